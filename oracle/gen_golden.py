@@ -1,0 +1,271 @@
+"""Generate tests/golden/*.npz by RUNNING THE REAL REFERENCE (imported from /root/reference) on CPU.
+
+Run once in the build container:   python oracle/gen_golden.py [micro|deit_small|deit_tiny_fp|kat|all]
+
+Nothing of the reference is copied: only its inputs and outputs (data) are stored.  The reference
+hard-codes ``.cuda()`` in its forward (e.g. models/vit_fquant.py:206, quantizer/uniform.py:85), which
+raises an ordinary ``RuntimeError: No HIP GPUs are available`` here; this script installs a
+process-local identity for ``Tensor.cuda`` (the reference tree is untouched).  Weights and images come
+from the build-owned deterministic generator ``diff-vit_amd/synth.py`` so full-size fixtures only need
+to store seeds + outputs.
+"""
+import importlib.util
+import os
+import sys
+import time
+from functools import partial
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+synth = _load('p2v_synth', os.path.join(ROOT, 'diff-vit_amd', 'synth.py'))
+oracle = _load('p2vit_oracle', os.path.join(ROOT, 'oracle', 'p2vit_oracle.py'))
+
+
+def import_reference():
+    torch.Tensor.cuda = lambda self, *a, **k: self      # process-local; see module docstring
+    sys.path.insert(0, '/root/reference')
+    import config as ref_config                           # noqa
+    import models as ref_models                           # noqa
+    from models import vit_fquant                         # noqa
+    return ref_config, ref_models, vit_fquant
+
+
+def build_ref(arch, sd, ref):
+    ref_config, ref_models, vit_fquant = ref
+    cfg = ref_config.Config(True, True, 'minmax')
+    m = vit_fquant.VisionTransformer(
+        img_size=arch['img_size'], patch_size=arch['patch_size'], embed_dim=arch['embed_dim'],
+        depth=arch['depth'], num_heads=arch['num_heads'], num_classes=arch['num_classes'],
+        mlp_ratio=arch['mlp_ratio'], qkv_bias=True,
+        norm_layer=partial(ref_models.QIntLayerNorm, eps=1e-6), input_quant=True, cfg=cfg)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    m.eval()
+    return m
+
+
+TAP_SUFFIX = ('qact_input', 'patch_embed.qact', 'qact1', 'attn.qact0', 'attn.qact1', 'attn.qact_attn1',
+              'attn.log_int_softmax', 'attn.qact2', 'attn.qact3', 'mlp.qact0', 'mlp.qact1', 'mlp.qact2',
+              'qact2', 'qact4', 'act_out')
+
+
+def run_with_taps(model, x, bit_config, want=None):
+    """forward + integer codes of every QAct output (value / scale) and LIS exponents."""
+    taps, hooks = {}, []
+
+    def mk(name, mod):
+        def hook(_m, _inp, out):
+            if name.endswith('log_int_softmax'):
+                k = torch.where(out > 0, -torch.log2(out.clamp(min=1e-30)), torch.full_like(out, 16.0))
+                taps[name.replace('log_int_softmax', 'softmax_k')] = k.round().to(torch.int8).numpy()
+            else:
+                s = mod.quantizer.scale
+                shp = oracle.act_shape(out)
+                taps[name] = torch.round(out / s.reshape(shp)).to(torch.int16).numpy()
+        return hook
+
+    for name, mod in model.named_modules():
+        if name.endswith(TAP_SUFFIX) and (want is None or want(name)):
+            hooks.append(mod.register_forward_hook(mk(name, mod)))
+    with torch.no_grad():
+        out, flops, gd = model(x, bit_config, False)
+    for h in hooks:
+        h.remove()
+    return out, flops, gd, taps
+
+
+def compare_oracle(tag, orc, x, bit_config, ref_out, ref_taps):
+    taps = {}
+    out = orc.quant_forward(x, bit_config, taps)
+    s_o = orc.calib['act_out']
+    dcode = torch.round((out - ref_out) / s_o).abs()
+    print('  [%s] logits: %d / %d codes differ (max |d|=%d); top1 equal: %s' % (
+        tag, int((dcode > 0).sum()), dcode.numel(), int(dcode.max()),
+        bool((out.argmax(1) == ref_out.argmax(1)).all())))
+    worst = []
+    for k, v in ref_taps.items():
+        if k in taps:
+            t = taps[k].reshape(v.shape).numpy().astype(np.int64)
+            n = int((t != v.astype(np.int64)).sum())
+            if n:
+                worst.append((k, n, v.size))
+    for k, n, sz in worst[:12]:
+        print('      tap %-34s %d / %d differ' % (k, n, sz))
+    if not worst:
+        print('      all %d taps bit-equal' % len(ref_taps))
+    return int((dcode > 0).sum())
+
+
+def gen_model_fixture(name, arch, seed, n_calib, n_eval, store_weights, tap_filter, ref):
+    t0 = time.time()
+    sd = synth.vit_state_dict(arch, seed)
+    model = build_ref(arch, sd, ref)
+    x_cal = synth.images(seed, n_calib, arch['img_size'])
+    x_ev = synth.images(seed, n_eval, arch['img_size'], offset=1000)
+    L = 4 * arch['depth'] + 2
+    mixed = [8 if (i * 7 + 3) % 5 < 3 else 4 for i in range(L)]
+    cfgs = {'q8': [8] * L, 'q4': [4] * L, 'qmix': mixed}
+    out = {'seed': np.int64(seed), 'n_calib': np.int64(n_calib), 'n_eval': np.int64(n_eval),
+           'bit_qmix': np.array(mixed, dtype=np.int8)}
+    with torch.no_grad():
+        fp, flops, gd = model(x_ev)                   # float forward before any calibration
+        out['fp_logits'] = fp.numpy()
+        out['flops'] = np.array(flops, dtype=np.int64)
+        model.model_open_calibrate()
+        model.model_open_last_calibrate()
+        cal, _, gd = model(x_cal, plot=False)
+        model.model_close_calibrate()
+        model.model_quant()
+    print('%s: reference calibrated in %.1fs' % (name, time.time() - t0))
+    out['calib_logits'] = cal.numpy()
+    out['global_distance'] = np.array([[float(v) for v in row] for row in gd], dtype=np.float64)
+    calib = oracle.extract_calib(model)
+    for k, v in oracle.flatten_calib(calib).items():
+        out['calib/' + k] = v.numpy()
+    orc = oracle.OracleViT(arch, sd)
+    orc.calib = calib
+    for tag, bc in cfgs.items():
+        o, fl, gd2, taps = run_with_taps(model, x_ev, bc, tap_filter)
+        assert gd2 == [] and fl == list(out['flops'])
+        out['logits/' + tag] = o.numpy()
+        out['top5/' + tag] = o.topk(min(5, o.shape[1]), 1, True, True)[1].numpy()
+        if tag != 'q4':
+            for k, v in taps.items():
+                out['taps/%s/%s' % (tag, k)] = v.astype(np.int8) if np.abs(v).max() < 128 else v
+        compare_oracle(name + '/' + tag, orc, x_ev, bc, o, taps)
+    # float pass parity of the oracle restatement
+    print('  oracle float_forward max|d| = %.3g' % float((orc.float_forward(x_ev) - fp).abs().max()))
+    if store_weights:
+        for k, v in sd.items():
+            out['w/' + k] = v.numpy()
+        out['x_cal'] = x_cal.numpy()
+        out['x_ev'] = x_ev.numpy()
+    os.makedirs(GOLD, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **out)
+    print('%s: wrote fixture (%.1fs total)' % (name, time.time() - t0))
+
+
+def gen_kat(ref):
+    """per-operator known-answer vectors straight from the reference classes."""
+    _, ref_models, _ = ref
+    from models.ptq.observer import build_observer
+    from models.ptq.quantizer import build_quantizer
+    from models.ptq.bit_type import BIT_TYPE_DICT
+    out = {}
+    # UniformQuantizer: ties (half to even), clamp edges, per-channel scales
+    x = torch.tensor([[-3.5, -2.5, -1.5, -0.5, 0.5, 1.5, 2.5, 3.5, 127.5, 128.5, -128.5, -129.5, 1e6, -1e6, 0.49999997, 7.5]])
+    x = torch.cat([x, synth.normal(1, 'kat/uq', (7, 16), 40.0)])
+    for bt in ('int8', 'int4', 'uint4'):
+        ob = build_observer('minmax', 'activation', BIT_TYPE_DICT[bt], 'channel_wise')
+        qz = build_quantizer('uniform', BIT_TYPE_DICT[bt], ob, 'activation')
+        qz.scale = torch.tensor([1.0, 0.5, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.25])
+        qz.zero_point = torch.zeros(16, dtype=torch.int64)
+        out['uq/%s/out' % bt] = qz(x).numpy()
+    out['uq/x'] = x.numpy()
+    out['uq/scale'] = qz.scale.numpy()
+    # QIntSoftmax on int8-grid scores for several PoT scaling factors, incl. a -100 style masked row
+    for e in range(3, 9):
+        sf = torch.tensor([2.0 ** -e])
+        codes = torch.round(synth.normal(2, 'kat/sm%d' % e, (2, 3, 37, 37), 45.0)).clamp(-128, 127)
+        codes[0, 0, 0, :] = -128
+        codes[0, 0, 0, 5] = 127
+        codes[0, 0, 1, :] = 17
+        codes[0, 1, 2, 10:] = -128
+        sm = ref_models.QIntSoftmax(log_i_softmax=True, bit_type=BIT_TYPE_DICT['uint4'], quantizer_str='log2')
+        p = sm(codes * sf, sf)
+        out['lis/%d/codes' % e] = codes.to(torch.int8).numpy()
+        out['lis/%d/probs' % e] = p.numpy()
+    # QIntLayerNorm.forward mode 'int' with PTF-style input scales, plus get_MN
+    for tag, C, expand in (('a', 96, 1), ('b', 64, 4)):
+        ln = ref_models.QIntLayerNorm(C)
+        ln.weight.data = synth.uniform(3, 'kat/ln%s/g' % tag, (C,), -1.5, 1.5)
+        ln.bias.data = synth.normal(3, 'kat/ln%s/b' % tag, (C,), 0.3)
+        ln.mode = 'int'
+        nin = C // expand
+        base = 0.0123
+        mask = 2.0 ** torch.floor(synth.uniform(3, 'kat/ln%s/m' % tag, (nin,), 0, 3.99))
+        class Q: pass
+        qi, qo = Q(), Q()
+        qi.scale = base * mask
+        qo.scale = torch.tensor([2.0 ** -4])
+        full = qi.scale if expand == 1 else qi.scale.unsqueeze(-1).expand(-1, expand).T.reshape(-1)
+        codes = torch.round(synth.normal(3, 'kat/ln%s/x' % tag, (3, 11, C), 35.0)).clamp(-128, 127)
+        codes[0, 0] = torch.round(codes[0, 0] * 0.02)
+        cs = 2.0 ** torch.floor(synth.uniform(3, 'kat/ln%s/cs' % tag, (C,), -2, 2.99))
+        y = ln(codes * full.reshape(1, 1, -1), qi, qo, cs, expand)
+        out['ln/%s/codes' % tag] = codes.to(torch.int8).numpy()
+        out['ln/%s/in_scale' % tag] = qi.scale.numpy()
+        out['ln/%s/out_scale' % tag] = (qo.scale * cs).numpy()
+        out['ln/%s/gamma' % tag] = ln.weight.data.numpy()
+        out['ln/%s/beta' % tag] = ln.bias.data.numpy()
+        out['ln/%s/out' % tag] = y.detach().numpy()
+        out['ln/%s/expand' % tag] = np.int64(expand)
+    A = torch.tensor([1e-9, 3e-5, 0.0078125, 0.3, 0.99999994, 1.0, 1.5, 127.9, 128.0, 255.5, 256.0, 1e5])
+    M, N = ln.get_MN(A)
+    out['mn/A'], out['mn/M'], out['mn/N'] = A.numpy(), M.numpy(), N.numpy()
+    # MinmaxObserver PoT search: activation (layer-wise int8), linear weight (int8 layer / int4 channel)
+    xa = synth.normal(4, 'kat/mm/x', (2, 9, 24), 1.7)
+    ob = build_observer('minmax', 'activation', BIT_TYPE_DICT['int8'], 'layer_wise')
+    ob.update(xa)
+    s, zp = ob.get_quantization_params(xa)
+    out['mm/act/x'], out['mm/act/scale'] = xa.numpy(), s.numpy()
+    w = synth.normal(4, 'kat/mm/w', (20, 24), 0.2)
+    b = synth.normal(4, 'kat/mm/b', (20,), 0.1)
+    out['mm/w'], out['mm/b'] = w.numpy(), b.numpy()
+    ob = build_observer('minmax', 'linear_weight', BIT_TYPE_DICT['int4'], 'channel_wise')
+    for bt in ('uint3', 'uint4', 'int4', 'int8'):
+        ob.bit_type = BIT_TYPE_DICT[bt]
+        ob.calibration_mode = 'layer_wise' if bt == 'int8' else 'channel_wise'
+        ob.update(w)
+        s, zp = ob.get_quantization_params(xa, others=[b])
+        out['mm/w/%s' % bt] = s.numpy()
+    # PtfObserver
+    xp = synth.normal(5, 'kat/ptf/x', (2, 13, 32), 1.0) * (2.0 ** torch.floor(synth.uniform(5, 'kat/ptf/m', (32,), 0, 3.99)))
+    ob = build_observer('ptf', 'activation', BIT_TYPE_DICT['int8'], 'channel_wise')
+    ob.update(xp)
+    s, zp = ob.get_quantization_params(xp)
+    out['ptf/x'], out['ptf/scale'] = xp.numpy(), s.numpy()
+    os.makedirs(GOLD, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLD, 'kat_ops.npz'), **out)
+    print('kat_ops: wrote %d arrays' % len(out))
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    torch.manual_seed(0)
+    ref = import_reference()
+    if what in ('kat', 'all'):
+        gen_kat(ref)
+    if what in ('micro', 'all'):
+        gen_model_fixture('micro_vit', synth.ARCHS['micro'], 7, 4, 6, True, None, ref)
+    if what in ('deit_tiny_fp', 'all'):
+        # BASELINE config 1 plumbing case: float forward only
+        arch = synth.ARCHS['deit_tiny']
+        sd = synth.vit_state_dict(arch, 11)
+        m = build_ref(arch, sd, ref)
+        x = synth.images(11, 4, 224, offset=1000)
+        with torch.no_grad():
+            fp, flops, _ = m(x)
+        np.savez_compressed(os.path.join(GOLD, 'deit_tiny_fp.npz'), seed=np.int64(11), fp_logits=fp.numpy(),
+                            flops=np.array(flops, dtype=np.int64))
+        print('deit_tiny_fp: wrote')
+    if what in ('deit_small', 'all'):
+        keep = lambda n: n.startswith(('blocks.0.', 'blocks.11.')) or '.' not in n or n.startswith('patch_embed')
+        gen_model_fixture('deit_small', synth.ARCHS['deit_small'], 3, 2, 2, False, keep, ref)
+
+
+if __name__ == '__main__':
+    main()
