@@ -1,0 +1,310 @@
+// p2vit_capi.cpp -- extern "C" surface of libp2vit_hip.so (see include/p2vit.h).
+//
+// The plan object is the frozen integer state the reference keeps in Python attributes after
+// model_close_calibrate(); model_quant() (test_quant.py:248-249): quantizer.scale / dic_scale / best_*
+// lists.  p2v_forward walks the graph of VisionTransformer.forward_features/forward
+// (models/vit_fquant.py:700-799) and enqueues 7 kernels per block on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "p2vit_kernels.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+static int launch_rc(int rc, const char* what) {
+  if (rc == 0) return 0;
+  if (rc < 0) return fail(P2V_E_UNSUPPORTED, "%s: no kernel instantiated for this shape", what);
+  return fail(P2V_E_LAUNCH, "%s: %s", what, hipGetErrorString((hipError_t)rc));
+}
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct p2v_plan {
+  p2v_model_desc d;
+  int tokens, patches, k_patch, k_patch_pad, n_layers;
+  std::vector<p2v_linear> lin[2];   // [bit index][layer]
+  std::vector<char> lin_set[2];
+  float inv_s_input;
+  p2v_epilogue embed_epi;
+  const int8_t* cls_codes;
+  bool embed_set;
+  std::vector<p2v_block> blocks;
+  std::vector<char> block_set;
+  p2v_ln final_ln;
+  float head_inv_s, head_s;
+  bool head_set;
+};
+
+static int bit_index(int bits) { return bits == 4 ? 0 : (bits == 8 ? 1 : -1); }
+
+extern "C" {
+
+int p2v_abi_version(void) { return P2V_ABI_VERSION; }
+const char* p2v_last_error(void) { return g_err; }
+
+int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
+  if (!desc || !out) return fail(P2V_E_ARG, "p2v_plan_create: null argument");
+  if (desc->abi_version != P2V_ABI_VERSION) return fail(P2V_E_ARG, "ABI version %d != %d", desc->abi_version, P2V_ABI_VERSION);
+  const p2v_model_desc& d = *desc;
+  if (d.img_size <= 0 || d.patch_size <= 0 || d.img_size % d.patch_size) return fail(P2V_E_SHAPE, "img_size %% patch_size != 0");
+  if (d.patch_size % 4) return fail(P2V_E_UNSUPPORTED, "patch_size must be a multiple of 4");
+  if (d.embed_dim % d.num_heads) return fail(P2V_E_SHAPE, "embed_dim %% num_heads != 0");
+  const int hd = d.embed_dim / d.num_heads;
+  if (hd != 32 && hd != 64) return fail(P2V_E_UNSUPPORTED, "head_dim %d (32 and 64 are instantiated)", hd);
+  if (d.embed_dim % 64 || d.mlp_hidden % 64) return fail(P2V_E_UNSUPPORTED, "embed_dim and mlp_hidden must be multiples of 64");
+  p2v_plan* p = new p2v_plan();
+  p->d = d;
+  p->patches = (d.img_size / d.patch_size) * (d.img_size / d.patch_size);
+  p->tokens = p->patches + 1;
+  p->k_patch = d.in_chans * d.patch_size * d.patch_size;
+  p->k_patch_pad = round_up(p->k_patch, GBK_PAD);
+  p->n_layers = 4 * d.depth + 2;
+  for (int b = 0; b < 2; ++b) {
+    p->lin[b].assign(p->n_layers, p2v_linear{nullptr, nullptr, nullptr});
+    p->lin_set[b].assign(p->n_layers, 0);
+  }
+  p->blocks.resize(d.depth);
+  p->block_set.assign(d.depth, 0);
+  p->embed_set = p->head_set = false;
+  p->cls_codes = nullptr;
+  *out = p;
+  return P2V_OK;
+}
+
+void p2v_plan_destroy(p2v_plan* plan) { delete plan; }
+
+int p2v_plan_set_linear(p2v_plan* plan, int layer, int bits, const p2v_linear* lin) {
+  if (!plan || !lin) return fail(P2V_E_ARG, "p2v_plan_set_linear: null argument");
+  const int bi = bit_index(bits);
+  if (bi < 0) return fail(P2V_E_BITS, "bits %d not in {4, 8}", bits);
+  if (layer < 0 || layer >= plan->n_layers) return fail(P2V_E_ARG, "layer %d out of range [0,%d)", layer, plan->n_layers);
+  if (!lin->w_codes || !lin->colscale || !lin->bias) return fail(P2V_E_ARG, "p2v_plan_set_linear: null device pointer");
+  plan->lin[bi][layer] = *lin;
+  plan->lin_set[bi][layer] = 1;
+  return P2V_OK;
+}
+
+int p2v_plan_set_embed(p2v_plan* plan, float inv_s_input, const p2v_epilogue* e, const int8_t* cls_row_codes) {
+  if (!plan || !e || !cls_row_codes) return fail(P2V_E_ARG, "p2v_plan_set_embed: null argument");
+  plan->inv_s_input = inv_s_input;
+  plan->embed_epi = *e;
+  plan->embed_epi.patches = plan->patches;
+  plan->cls_codes = cls_row_codes;
+  plan->embed_set = true;
+  return P2V_OK;
+}
+
+int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk) {
+  if (!plan || !blk) return fail(P2V_E_ARG, "p2v_plan_set_block: null argument");
+  if (block < 0 || block >= plan->d.depth) return fail(P2V_E_ARG, "block %d out of range", block);
+  plan->blocks[block] = *blk;
+  plan->block_set[block] = 1;
+  return P2V_OK;
+}
+
+int p2v_plan_set_head(p2v_plan* plan, const p2v_ln* final_ln, float inv_s_out, float s_out) {
+  if (!plan || !final_ln) return fail(P2V_E_ARG, "p2v_plan_set_head: null argument");
+  plan->final_ln = *final_ln;
+  plan->head_inv_s = inv_s_out;
+  plan->head_s = s_out;
+  plan->head_set = true;
+  return P2V_OK;
+}
+
+// workspace: [patches | x | ln | qkv | att | hid | cls], each 256-byte aligned
+struct WsLayout {
+  size_t patches, x, ln, qkv, att, hid, cls, total;
+};
+static WsLayout ws_layout(const p2v_plan* p, int batch) {
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t M = (size_t)batch * p->tokens, D = p->d.embed_dim;
+  WsLayout w;
+  size_t off = 0;
+  w.patches = off; off += al((size_t)batch * p->patches * p->k_patch_pad);
+  w.x = off;       off += al(M * D);
+  w.ln = off;      off += al(M * D);
+  w.qkv = off;     off += al(M * 3 * D);
+  w.att = off;     off += al(M * D);
+  w.hid = off;     off += al(M * (size_t)p->d.mlp_hidden);
+  w.cls = off;     off += al((size_t)batch * D);
+  w.total = off;
+  return w;
+}
+
+size_t p2v_workspace_bytes(const p2v_plan* plan, int batch) {
+  if (!plan || batch <= 0) return 0;
+  return ws_layout(plan, batch).total;
+}
+
+long long p2v_workspace_view(const p2v_plan* plan, int batch, const char* name) {
+  if (!plan || !name || batch <= 0) return -1;
+  WsLayout w = ws_layout(plan, batch);
+  if (!strcmp(name, "patches")) return (long long)w.patches;
+  if (!strcmp(name, "x")) return (long long)w.x;
+  if (!strcmp(name, "ln")) return (long long)w.ln;
+  if (!strcmp(name, "qkv")) return (long long)w.qkv;
+  if (!strcmp(name, "att")) return (long long)w.att;
+  if (!strcmp(name, "hid")) return (long long)w.hid;
+  if (!strcmp(name, "cls")) return (long long)w.cls;
+  return -1;
+}
+
+static int run_gemm(int epi, const int8_t* A, int lda, int M, int K, int N, const p2v_linear& lin, const p2v_epilogue& ep, void* out,
+                    int ldo, int8_t* out_codes, hipStream_t st) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.M = M; g.W = lin.w_codes; g.K = K; g.N = N;
+  g.colscale = lin.colscale; g.bias = lin.bias; g.ep = ep; g.out = out; g.ldo = ldo; g.out_codes = out_codes; g.tiles_n = 0;
+  return launch_rc(p2v_launch_gemm(epi, g, st), "gemm_i8");
+}
+
+int p2v_forward(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
+                size_t workspace_bytes, int stop_after, void* stream) {
+  if (!p || !images || !bit_config || !logits || !workspace) return fail(P2V_E_ARG, "p2v_forward: null argument");
+  if (batch <= 0) return fail(P2V_E_SHAPE, "batch must be positive");
+  if (n_cfg != p->n_layers) return fail(P2V_E_BITS, "bit_config has %d entries, model needs %d", n_cfg, p->n_layers);
+  for (int i = 0; i < n_cfg; ++i) {
+    const int bi = bit_index(bit_config[i]);
+    if (bi < 0) return fail(P2V_E_BITS, "%d is not in list", (int)bit_config[i]);   // bit_pool.index, vit_fquant.py:282
+    if (!p->lin_set[bi][i]) return fail(P2V_E_STATE, "layer %d has no %d-bit weights", i, (int)bit_config[i]);
+  }
+  if (!p->embed_set || !p->head_set) return fail(P2V_E_STATE, "plan incomplete (embed/head)");
+  for (int i = 0; i < p->d.depth; ++i)
+    if (!p->block_set[i]) return fail(P2V_E_STATE, "plan incomplete (block %d)", i);
+  const WsLayout w = ws_layout(p, batch);
+  if (workspace_bytes < w.total) return fail(P2V_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, w.total);
+  hipStream_t st = (hipStream_t)stream;
+  int8_t* ws = reinterpret_cast<int8_t*>(workspace);
+  int8_t *bufP = ws + w.patches, *bufX = ws + w.x, *bufLN = ws + w.ln, *bufQKV = ws + w.qkv, *bufATT = ws + w.att,
+         *bufHID = ws + w.hid, *bufCLS = ws + w.cls;
+  const p2v_model_desc& d = p->d;
+  const int D = d.embed_dim, T = p->tokens, M = batch * T, Hd = d.mlp_hidden, hd = D / d.num_heads;
+  int launched = 0, rc;
+#define STEP(call)                                    \
+  do {                                                \
+    if (stop_after >= 0 && launched >= stop_after) return P2V_OK; \
+    rc = (call);                                      \
+    if (rc) return rc;                                \
+    ++launched;                                       \
+  } while (0)
+
+  // qact_input + PatchEmbed + cls/pos/qact1                                 vit_fquant.py:705-733
+  STEP(launch_rc(p2v_launch_patchify(images, batch, d.in_chans, d.img_size, d.img_size, d.patch_size, p->inv_s_input, bufP,
+                                     p->k_patch_pad, st), "quantize_patchify"));
+  {
+    const p2v_linear& l = p->lin[bit_index(bit_config[0])][0];
+    STEP(run_gemm(P2V_EPI_EMBED, bufP, p->k_patch_pad, batch * p->patches, p->k_patch_pad, D, l, p->embed_epi, bufX, D, nullptr, st));
+  }
+  STEP(launch_rc(p2v_launch_fill_cls(bufX, batch, T, D, p->cls_codes, st), "fill_cls"));
+
+  for (int i = 0; i < d.depth; ++i) {
+    const p2v_block& b = p->blocks[i];
+    const int8_t* bc = bit_config + 1 + 4 * i;
+    const int bq = bit_index(bc[0]), bp = bit_index(bc[1]), b1 = bit_index(bc[2]), b2 = bit_index(bc[3]);
+    // norm1 -> /channel_scale -> qact0                                     vit_fquant.py:431-434,284-289
+    LnArgs ln{bufX, D, M, D, b.ln1[bq], bufLN, D};
+    STEP(launch_rc(p2v_launch_layernorm(ln, st), "int_layernorm"));
+    // qkv -> qact1                                                          vit_fquant.py:293,307
+    p2v_epilogue e{};
+    e.inv_s_out = b.inv_s_qkv[bq];
+    STEP(run_gemm(P2V_EPI_REQUANT, bufLN, D, M, D, 3 * D, p->lin[bq][1 + 4 * i], e, bufQKV, 3 * D, nullptr, st));
+    // scores -> qact_attn1 -> log-int-softmax -> @v -> qact2                vit_fquant.py:309-326
+    AttnArgs at{bufQKV, batch, T, d.num_heads, b.attn, bufATT, nullptr};
+    STEP(launch_rc(p2v_launch_attention(at, hd, st), "lis_attention"));
+    // proj -> qact3 -> + x -> Block.qact2                                   vit_fquant.py:334-338,431
+    p2v_epilogue ep = b.proj_epi;
+    ep.residual = bufX;
+    STEP(run_gemm(P2V_EPI_RESID, bufATT, D, M, D, D, p->lin[bp][2 + 4 * i], ep, bufX, D, nullptr, st));
+    // norm2 (attention's channel scale!) -> /mlp.channel_scale -> mlp.qact0 vit_fquant.py:464, layers_quant.py:305-311
+    LnArgs ln2{bufX, D, M, D, b.ln2[bq][b1], bufLN, D};
+    STEP(launch_rc(p2v_launch_layernorm(ln2, st), "int_layernorm"));
+    // fc1 -> GELU -> qact1                                                  layers_quant.py:316,331-333
+    p2v_epilogue e1{};
+    e1.inv_s_out = b.inv_s_fc1;
+    STEP(run_gemm(P2V_EPI_GELU, bufLN, D, M, D, Hd, p->lin[b1][3 + 4 * i], e1, bufHID, Hd, nullptr, st));
+    // fc2 -> qact2 -> + x -> Block.qact4                                    layers_quant.py:342-346, vit_fquant.py:468
+    p2v_epilogue e2 = b.fc2_epi;
+    e2.residual = bufX;
+    STEP(run_gemm(P2V_EPI_RESID, bufHID, Hd, M, Hd, D, p->lin[b2][4 + 4 * i], e2, bufX, D, nullptr, st));
+  }
+  // norm over the cls rows only ([:,0]) -> qact2 -> head -> act_out         vit_fquant.py:766-796
+  LnArgs lf{bufX, (long long)T * D, batch, D, p->final_ln, bufCLS, D};
+  STEP(launch_rc(p2v_launch_layernorm(lf, st), "int_layernorm"));
+  p2v_epilogue eh{};
+  eh.inv_s_out = p->head_inv_s;
+  eh.s_out = p->head_s;
+  STEP(run_gemm(P2V_EPI_HEAD, bufCLS, D, batch, D, d.num_classes, p->lin[bit_index(bit_config[n_cfg - 1])][n_cfg - 1], eh, logits,
+                d.num_classes, nullptr, st));
+#undef STEP
+  return P2V_OK;
+}
+
+// ---- per-operator entry points ------------------------------------------------------------------------
+int p2v_quantize_patchify(const float* img, int batch, int chans, int height, int width, int patch, float inv_s, int8_t* out,
+                          int k_pad, void* stream) {
+  if (!img || !out) return fail(P2V_E_ARG, "p2v_quantize_patchify: null argument");
+  if (patch <= 0 || patch % 4 || height % patch || width % patch) return fail(P2V_E_SHAPE, "image %dx%d not divisible into %d-patches", height, width, patch);
+  if (k_pad % 4 || k_pad < chans * patch * patch) return fail(P2V_E_ARG, "k_pad %d too small / unaligned", k_pad);
+  return launch_rc(p2v_launch_patchify(img, batch, chans, height, width, patch, inv_s, out, k_pad, (hipStream_t)stream), "quantize_patchify");
+}
+
+int p2v_gemm_i8(int kind, const int8_t* A, int lda, int M, int K, int N, const p2v_linear* lin, const p2v_epilogue* epi, void* out,
+                int ldo, int8_t* out_codes, void* stream) {
+  if (!A || !lin || !epi || !out) return fail(P2V_E_ARG, "p2v_gemm_i8: null argument");
+  if (kind < P2V_EPI_REQUANT || kind > P2V_EPI_HEAD) return fail(P2V_E_ARG, "unknown epilogue %d", kind);
+  if (M <= 0 || N <= 0 || K <= 0 || K % GBK_PAD) return fail(P2V_E_SHAPE, "K=%d must be a positive multiple of %d", K, GBK_PAD);
+  if (kind != P2V_EPI_HEAD && (N % 16 || ldo % 16)) return fail(P2V_E_UNSUPPORTED, "N and ldo must be multiples of 16 for int8 outputs");
+  if (lda % 16) return fail(P2V_E_UNSUPPORTED, "lda must be a multiple of 16");
+  if (kind == P2V_EPI_RESID && (!epi->s_mid || !epi->s_res || !epi->s_next || !epi->residual)) return fail(P2V_E_ARG, "RESID epilogue needs s_mid/s_res/s_next/residual");
+  if (kind == P2V_EPI_EMBED && (!epi->s_next || !epi->pos_deq || epi->patches <= 0)) return fail(P2V_E_ARG, "EMBED epilogue needs s_next/pos_deq/patches");
+  return run_gemm(kind, A, lda, M, K, N, *lin, *epi, out, ldo, out_codes, (hipStream_t)stream);
+}
+
+int p2v_int_layernorm(const int8_t* x, long long row_stride, int rows, int C, const p2v_ln* ln, int8_t* out, long long out_stride,
+                      void* stream) {
+  if (!x || !ln || !out) return fail(P2V_E_ARG, "p2v_int_layernorm: null argument");
+  if (C % 4 || row_stride % 4 || out_stride % 4) return fail(P2V_E_UNSUPPORTED, "C and strides must be multiples of 4");
+  if (rows <= 0) return fail(P2V_E_SHAPE, "rows must be positive");
+  LnArgs a{x, row_stride, rows, C, *ln, out, out_stride};
+  return launch_rc(p2v_launch_layernorm(a, (hipStream_t)stream), "int_layernorm");
+}
+
+int p2v_lis_attention(const int8_t* qkv, int batch, int tokens, int heads, int head_dim, const p2v_attn* at, int8_t* out,
+                      int8_t* probs_k, void* stream) {
+  if (!qkv || !at || !out) return fail(P2V_E_ARG, "p2v_lis_attention: null argument");
+  if (batch <= 0 || tokens <= 0 || heads <= 0) return fail(P2V_E_SHAPE, "bad attention shape");
+  if (at->x0_int >= 0) return fail(P2V_E_ARG, "x0_int must be negative");
+  AttnArgs a{qkv, batch, tokens, heads, *at, out, probs_k};
+  return launch_rc(p2v_launch_attention(a, head_dim, (hipStream_t)stream), "lis_attention");
+}
+
+int p2v_fake_quant_f32(const float* x, long long n, const float* scale, int n_scale, long long inner, int lo, int hi, float* out,
+                       int8_t* codes, void* stream) {
+  if (!x || !scale || (!out && !codes)) return fail(P2V_E_ARG, "p2v_fake_quant_f32: null argument");
+  if (n_scale < 1 || inner < 1) return fail(P2V_E_ARG, "n_scale and inner must be >= 1");
+  if (n == 0) return P2V_OK;
+  return launch_rc(p2v_launch_fake_quant(x, n, scale, n_scale, inner, lo, hi, out, codes, (hipStream_t)stream), "fake_quant");
+}
+
+int p2v_gelu_quant_f32(const float* y, long long n, float inv_s, int8_t* codes, unsigned long long* flags, int force_slow,
+                       void* stream) {
+  if (!y || !codes) return fail(P2V_E_ARG, "p2v_gelu_quant_f32: null argument");
+  if (n == 0) return P2V_OK;
+  return launch_rc(p2v_launch_gelu_quant(y, n, inv_s, codes, flags, force_slow, (hipStream_t)stream), "gelu_quant");
+}
+
+int p2v_gelu_err_sweep(unsigned first_bits, unsigned count, float* max_err, void* stream) {
+  if (!max_err) return fail(P2V_E_ARG, "p2v_gelu_err_sweep: null argument");
+  return launch_rc(p2v_launch_gelu_sweep(first_bits, count, max_err, (hipStream_t)stream), "gelu_sweep");
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// internal launch interface between the C ABI (p2vit_capi.cpp) and the kernels (p2vit_kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/p2vit.h"
+
+#define GBK_PAD 64   // K granularity of the GEMM tiles: weights/activations are padded to this
+
+struct GemmArgs {
+  const int8_t* A;      // activations [M][lda] int8
+  int lda, M;
+  const int8_t* W;      // weight codes [n_pad][K] int8
+  int K, N;
+  const float* colscale;
+  const float* bias;
+  p2v_epilogue ep;
+  void* out;
+  int ldo;
+  int8_t* out_codes;
+  int tiles_n;          // filled by the launcher
+};
+
+struct LnArgs {
+  const int8_t* x;
+  long long row_stride;
+  long long rows;
+  int C;
+  p2v_ln ln;
+  int8_t* out;
+  long long out_stride;
+};
+
+struct AttnArgs {
+  const int8_t* qkv;
+  int B, N, H;
+  p2v_attn at;
+  int8_t* out;
+  int8_t* probs_k;
+};
+
+int p2v_launch_patchify(const float* img, int B, int C, int H, int W, int P, float inv_s, int8_t* out, int k_pad, hipStream_t st);
+int p2v_launch_fill_cls(int8_t* x, int B, int T, int D, const int8_t* cls, hipStream_t st);
+int p2v_launch_gemm(int epi, const GemmArgs& g, hipStream_t st);
+int p2v_launch_layernorm(const LnArgs& a, hipStream_t st);
+int p2v_launch_attention(const AttnArgs& a, int head_dim, hipStream_t st);
+int p2v_launch_fake_quant(const float* x, long long n, const float* scale, int n_scale, long long inner, int lo, int hi,
+                          float* out, int8_t* codes, hipStream_t st);
+int p2v_launch_gelu_quant(const float* y, long long n, float inv_s, int8_t* codes, unsigned long long* flags, int force_slow,
+                          hipStream_t st);
+int p2v_launch_gelu_sweep(unsigned first_bits, unsigned count, float* max_err, hipStream_t st);

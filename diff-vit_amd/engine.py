@@ -1,0 +1,116 @@
+"""ctypes binding of the C-ABI engine ``csrc/libp2vit_hip.so`` (declared in ``include/p2vit.h``).
+
+The library is the product: there is no eager/CPU fallback.  Anything that needs the quantized forward
+calls :func:`lib`, which raises ``RuntimeError`` when the shared object has not been built
+(``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C diff-vit_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libp2vit_hip.so')
+
+P2V_ABI_VERSION = 1
+EPI_REQUANT, EPI_GELU, EPI_RESID, EPI_EMBED, EPI_HEAD = 0, 1, 2, 3, 4
+E_ARG, E_BITS, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH, E_STATE = -1, -2, -3, -4, -5, -6, -7
+
+_f, _i, _p, _ll = C.c_float, C.c_int32, C.c_void_p, C.c_longlong
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [('abi_version', _i), ('img_size', _i), ('patch_size', _i), ('in_chans', _i), ('embed_dim', _i),
+                ('depth', _i), ('num_heads', _i), ('mlp_hidden', _i), ('num_classes', _i)]
+
+
+class Linear(C.Structure):
+    _fields_ = [('w_codes', _p), ('colscale', _p), ('bias', _p)]
+
+
+class Ln(C.Structure):
+    _fields_ = [('s1', _f), ('mask', _p), ('gamma', _p), ('beta', _p), ('inv_out', _p), ('post_mul', _p)]
+
+
+class Attn(C.Structure):
+    _fields_ = [('s_qkv_sq', _f), ('qk_scale', _f), ('inv_s_attn', _f), ('av_mul', _f), ('x0_int', _i), ('b_int', _i),
+                ('c_int', _i)]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [('inv_s_out', _f), ('s_out', _f), ('s_mid', _p), ('s_res', _p), ('s_next', _p), ('residual', _p),
+                ('inv_s_pe', _f), ('pe_to_embed', _f), ('s_embed', _f), ('pos_deq', _p), ('patches', _i)]
+
+
+class Block(C.Structure):
+    _fields_ = [('ln1', Ln * 2), ('inv_s_qkv', _f * 2), ('attn', Attn), ('proj_epi', Epilogue), ('ln2', (Ln * 2) * 2),
+                ('inv_s_fc1', _f), ('fc2_epi', Epilogue)]
+
+
+class P2VError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """Load (once) and return the engine library; loud failure when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('HIP engine %s is not built: run `make -C %s` (or __graft_entry__.build()). '
+                           'The quantized forward has no CPU fallback.' % (LIB_PATH, os.path.dirname(LIB_PATH)))
+    L = C.CDLL(LIB_PATH)
+    L.p2v_last_error.restype = C.c_char_p
+    L.p2v_abi_version.restype = _i
+    L.p2v_plan_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(_p)]
+    L.p2v_plan_destroy.argtypes = [_p]
+    L.p2v_plan_destroy.restype = None
+    L.p2v_plan_set_linear.argtypes = [_p, _i, _i, C.POINTER(Linear)]
+    L.p2v_plan_set_embed.argtypes = [_p, _f, C.POINTER(Epilogue), _p]
+    L.p2v_plan_set_block.argtypes = [_p, _i, C.POINTER(Block)]
+    L.p2v_plan_set_head.argtypes = [_p, C.POINTER(Ln), _f, _f]
+    L.p2v_workspace_bytes.argtypes = [_p, _i]
+    L.p2v_workspace_bytes.restype = C.c_size_t
+    L.p2v_workspace_view.argtypes = [_p, _i, C.c_char_p]
+    L.p2v_workspace_view.restype = _ll
+    L.p2v_forward.argtypes = [_p, _p, _i, C.POINTER(C.c_int8), _i, _p, _p, C.c_size_t, _i, _p]
+    L.p2v_quantize_patchify.argtypes = [_p, _i, _i, _i, _i, _i, _f, _p, _i, _p]
+    L.p2v_gemm_i8.argtypes = [_i, _p, _i, _i, _i, _i, C.POINTER(Linear), C.POINTER(Epilogue), _p, _i, _p, _p]
+    L.p2v_int_layernorm.argtypes = [_p, _ll, _i, _i, C.POINTER(Ln), _p, _ll, _p]
+    L.p2v_lis_attention.argtypes = [_p, _i, _i, _i, _i, C.POINTER(Attn), _p, _p, _p]
+    L.p2v_fake_quant_f32.argtypes = [_p, _ll, _p, _i, _ll, _i, _i, _p, _p, _p]
+    L.p2v_gelu_quant_f32.argtypes = [_p, _ll, _f, _p, _p, _i, _p]
+    L.p2v_gelu_err_sweep.argtypes = [C.c_uint32, C.c_uint32, _p, _p]
+    if L.p2v_abi_version() != P2V_ABI_VERSION:
+        raise RuntimeError('libp2vit_hip.so ABI %d != binding %d: rebuild' % (L.p2v_abi_version(), P2V_ABI_VERSION))
+    _lib = L
+    return L
+
+
+def check(rc):
+    """Map C status codes onto the exceptions the reference raises at the same places."""
+    if rc == 0:
+        return
+    msg = lib().p2v_last_error().decode()
+    if rc == E_BITS:
+        raise ValueError(msg)                      # bit_pool.index(bit) -> ValueError (vit_fquant.py:282)
+    if rc == E_SHAPE:
+        raise AssertionError(msg)                  # PatchEmbed size assert (layers_quant.py:437-439)
+    if rc == E_UNSUPPORTED:
+        raise NotImplementedError(msg)             # quantizer/base.py:28-30
+    raise P2VError('p2vit error %d: %s' % (rc, msg))
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,255 @@
+"""Freeze a calibrated PoT-PTQ ViT into the integer plan the HIP engine executes.
+
+The reference keeps its calibrated state in Python attributes (``quantizer.scale``, ``dic_scale``,
+``best_scale/best_act_scale/best_weight_scale`` -- models/vit_fquant.py:234-239,273-278) and re-derives
+everything on every forward: weights are fake-quantised per call (models/ptq/layers.py:177,
+quantizer/uniform.py:82-88), LN multipliers and softmax constants are recomputed per call
+(layers.py:255-289,334-351).  Freezing does that work once, with the same fp32 operations, and uploads
+the result; ``forward`` then is one C call (``p2v_forward``).
+
+Input is a *calibration dict* (nested: name -> tensor | {bit_name: tensor} | [per-bit-pool-index ...]),
+the format ``export_calib`` produces from the module surface; plus the fp32 ``state_dict``.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import engine as E
+
+BIT_POOL = (4, 8)                                # models/vit_fquant.py:33
+BOUNDS = {4: (-8, 7), 8: (-128, 127)}            # models/ptq/bit_type.py:17-27 for int4 / int8
+GEMM_N_PAD, GEMM_K_PAD = 128, 64
+
+
+def _is_pot(t):
+    m, _ = torch.frexp(t.detach().float().reshape(-1))
+    return bool(torch.all(m == 0.5))
+
+
+def _need_pot(name, t):
+    if not _is_pot(t):
+        # the kernels replace x / s by exact multiplications with 1/s; only valid for PoT scales
+        raise NotImplementedError('%s is not a power of two (observer other than the PoT minmax?)' % name)
+    return t.detach().float()
+
+
+def _q8(v, s):
+    return torch.clamp(torch.round(v / s), -128, 127)
+
+
+def lis_consts(sf):
+    """x0_int, b_int, c_int with the reference's fp32 expressions (models/ptq/layers.py:334-351)."""
+    sf = sf.detach().float().reshape(())
+    x0 = torch.floor(-0.6931 / sf)
+    b = torch.floor((0.96963238 / 0.35815147) / sf)
+    c = torch.floor((1. / 0.35815147) / sf**2)
+    return int(x0), int(b), int(c)
+
+
+class FrozenPlan:
+    """Device-resident integer plan + handle of the C plan object."""
+
+    def __init__(self, arch, state_dict, calib, device='cuda', in_chans=3):
+        self.arch = dict(arch)
+        self.device = torch.device(device)
+        self.in_chans = in_chans
+        self._keep = []          # tensors whose device pointers the C plan borrows
+        self._handle = C.c_void_p()
+        self._ws = None
+        self._ws_batch = 0
+        a = self.arch
+        self.D, self.depth, self.H = a['embed_dim'], a['depth'], a['num_heads']
+        self.hidden = int(self.D * a['mlp_ratio'])
+        self.patches = (a['img_size'] // a['patch_size']) ** 2
+        self.tokens = self.patches + 1
+        self.n_layers = 4 * self.depth + 2
+        L = E.lib()
+        desc = E.ModelDesc(E.P2V_ABI_VERSION, a['img_size'], a['patch_size'], in_chans, self.D, self.depth, self.H,
+                           self.hidden, a['num_classes'])
+        E.check(L.p2v_plan_create(C.byref(desc), C.byref(self._handle)))
+        W = {k: v.detach().float().cpu() for k, v in state_dict.items()}
+        self._build(W, calib)
+
+    # ---------------------------------------------------------------------------------------------
+    def _dev(self, t, dtype=torch.float32):
+        t = t.detach().to(dtype).contiguous().to(self.device)
+        self._keep.append(t)
+        return t
+
+    def _linear(self, layer, w, cs, s_x, dic, bias):
+        """QLinear/QConv2d weight for both bit widths (layers.py:173-178; uniform.py:82-88)."""
+        L = E.lib()
+        w2 = w.reshape(w.shape[0], -1)
+        if cs is not None:
+            w2 = w2 * cs.reshape((1, -1))                    # weight_smoothed, vit_fquant.py:285
+        N, K = w2.shape
+        n_pad = (N + GEMM_N_PAD - 1) // GEMM_N_PAD * GEMM_N_PAD
+        k_pad = (K + GEMM_K_PAD - 1) // GEMM_K_PAD * GEMM_K_PAD
+        for bits in BIT_POOL:
+            name = 'int%d' % bits
+            s_w = _need_pot('%d.%s weight scale' % (layer, name), dic[name]).reshape(-1)
+            lo, hi = BOUNDS[bits]
+            codes = torch.clamp(torch.round(w2 / s_w.reshape(-1, 1)), lo, hi)
+            wp = torch.zeros(n_pad, k_pad, dtype=torch.int8)
+            wp[:N, :K] = codes.to(torch.int8)
+            cs_col = torch.zeros(n_pad)
+            cs_col[:N] = (s_x.reshape(-1) * s_w).expand(N)
+            bp = torch.zeros(n_pad)
+            if bias is not None:
+                bp[:N] = bias
+            lin = E.Linear(E.ptr(self._dev(wp, torch.int8)), E.ptr(self._dev(cs_col)), E.ptr(self._dev(bp)))
+            E.check(L.p2v_plan_set_linear(self._handle, layer, bits, C.byref(lin)))
+
+    def _ln(self, in_scale, gamma, beta, out_scale, post_mul):
+        """Constants of QIntLayerNorm mode 'int' (layers.py:255-289)."""
+        in_scale = in_scale.reshape(-1).float()
+        D = gamma.numel()
+        s1 = in_scale.min()
+        mask = torch.round(in_scale / s1).expand(D) if in_scale.numel() == 1 else torch.round(in_scale / s1)
+        out_scale = _need_pot('LN out scale', out_scale.reshape(-1).expand(D).contiguous())
+        post_mul = _need_pot('LN post multiplier', post_mul.reshape(-1).expand(D).contiguous())
+        return E.Ln(float(s1), E.ptr(self._dev(mask)), E.ptr(self._dev(gamma)), E.ptr(self._dev(beta)),
+                    E.ptr(self._dev(1.0 / out_scale)), E.ptr(self._dev(post_mul)))
+
+    def _build(self, W, c):
+        L = E.lib()
+        a, D = self.arch, self.D
+        hd = D // self.H
+        # ---- stem ------------------------------------------------------------------------------
+        s_in = _need_pot('qact_input', c['qact_input'])
+        self._linear(0, W['patch_embed.proj.weight'], None, s_in, c['patch_embed.proj'], W['patch_embed.proj.bias'])
+        s_pe = _need_pot('patch_embed.qact', c['patch_embed.qact'])
+        s_e = _need_pot('qact_embed', c['qact_embed'])
+        s_p = _need_pot('qact_pos', c['qact_pos'])
+        s_res = c['qact1'].detach().float().reshape(-1)                       # PTF: arbitrary fp32
+        pos_deq = (_q8(W['pos_embed'], s_p) * s_p).reshape(self.tokens, D)
+        cls_v = _q8(W['cls_token'].reshape(1, D), s_e) * s_e + pos_deq[0:1]   # vit_fquant.py:718-725
+        cls_codes = _q8(cls_v, s_res.reshape(1, -1)).reshape(D)
+        epi = E.Epilogue()
+        epi.inv_s_pe = float(1.0 / s_pe)
+        epi.pe_to_embed = float(s_pe / s_e)
+        epi.s_embed = float(s_e)
+        epi.s_next = E.ptr(self._dev(s_res))
+        epi.pos_deq = E.ptr(self._dev(pos_deq))
+        epi.patches = self.patches
+        E.check(L.p2v_plan_set_embed(self._handle, float(1.0 / s_in), C.byref(epi), E.ptr(self._dev(cls_codes, torch.int8))))
+        # ---- blocks ----------------------------------------------------------------------------
+        for i in range(self.depth):
+            p = 'blocks.%d.' % i
+            blk = E.Block()
+            cs_a, s_a0 = c[p + 'attn.best_scale'], c[p + 'attn.best_act_scale']
+            cs_m, s_m0 = c[p + 'mlp.best_scale'], c[p + 'mlp.best_act_scale']
+            g1, b1 = W[p + 'norm1.weight'], W[p + 'norm1.bias']
+            g2, b2 = W[p + 'norm2.weight'], W[p + 'norm2.bias']
+            s_b2 = c[p + 'qact2'].detach().float().reshape(-1)
+            s_b4 = c[p + 'qact4'].detach().float().reshape(-1)
+            s_q1 = _need_pot(p + 'attn.qact1', c[p + 'attn.qact1'])
+            s_at = _need_pot(p + 'attn.qact_attn1', c[p + 'attn.qact_attn1'])
+            s_a2 = _need_pot(p + 'attn.qact2', c[p + 'attn.qact2'])
+            s_m1 = _need_pot(p + 'mlp.qact1', c[p + 'mlp.qact1'])
+            for bi in range(2):
+                csb = _need_pot(p + 'attn.channel_scale', cs_a[bi])
+                sab = _need_pot(p + 'attn.qact0', s_a0[bi])
+                out_scale = sab * csb                                          # layers.py:264-265
+                blk.ln1[bi] = self._ln(s_res, g1, b1, out_scale, out_scale / csb / sab)
+                blk.inv_s_qkv[bi] = float(1.0 / s_q1)
+                for bm in range(2):
+                    csm = _need_pot(p + 'mlp.channel_scale', cs_m[bm])
+                    smb = _need_pot(p + 'mlp.qact0', s_m0[bm])
+                    o2 = smb * csb                                             # attention's scale: vit_fquant.py:464
+                    blk.ln2[bi][bm] = self._ln(s_b2, g2, b2, o2, o2 / csm / smb)
+            # qkv / fc1 depend on the bit-pool index through best_* (identical when |alpha_pool| == 1)
+            self._linear_per_bit(1 + 4 * i, W[p + 'attn.qkv.weight'], cs_a, s_a0, c[p + 'attn.best_weight_scale'], W[p + 'attn.qkv.bias'])
+            x0, bb, cc = lis_consts(s_at)
+            blk.attn = E.Attn(float(s_q1 * s_q1), float(np.float32(hd ** -0.5)), float(1.0 / s_at), float(s_q1 / s_a2), x0, bb, cc)
+            self._linear(2 + 4 * i, W[p + 'attn.proj.weight'], None, s_a2, c[p + 'attn.proj'], W[p + 'attn.proj.bias'])
+            pe = E.Epilogue()
+            pe.s_mid = E.ptr(self._dev(c[p + 'attn.qact3'].reshape(-1)))
+            pe.s_res = E.ptr(self._dev(s_res))
+            pe.s_next = E.ptr(self._dev(s_b2))
+            blk.proj_epi = pe
+            self._linear_per_bit(3 + 4 * i, W[p + 'mlp.fc1.weight'], cs_m, s_m0, c[p + 'mlp.best_weight_scale'], W[p + 'mlp.fc1.bias'])
+            blk.inv_s_fc1 = float(1.0 / s_m1)
+            self._linear(4 + 4 * i, W[p + 'mlp.fc2.weight'], None, s_m1, c[p + 'mlp.fc2'], W[p + 'mlp.fc2.bias'])
+            fe = E.Epilogue()
+            fe.s_mid = E.ptr(self._dev(c[p + 'mlp.qact2'].reshape(-1)))
+            fe.s_res = E.ptr(self._dev(s_b2))
+            fe.s_next = E.ptr(self._dev(s_b4))
+            blk.fc2_epi = fe
+            E.check(L.p2v_plan_set_block(self._handle, i, C.byref(blk)))
+            s_res = s_b4
+        # ---- head ------------------------------------------------------------------------------
+        s_f = _need_pot('qact2', c['qact2'])
+        s_o = _need_pot('act_out', c['act_out'])
+        fl = self._ln(s_res, W['norm.weight'], W['norm.bias'], s_f, s_f / s_f)
+        E.check(L.p2v_plan_set_head(self._handle, C.byref(fl), float(1.0 / s_o), float(s_o)))
+        self._linear(self.n_layers - 1, W['head.weight'], None, s_f, c['head'], W['head.bias'])
+        self.s_out = float(s_o)
+
+    def _linear_per_bit(self, layer, w, cs_list, s_x_list, dic_list, bias):
+        """qkv / fc1: SmoothQuant state is looked up per bit-pool index (vit_fquant.py:282-292)."""
+        L = E.lib()
+        N, K = w.shape
+        n_pad = (N + GEMM_N_PAD - 1) // GEMM_N_PAD * GEMM_N_PAD
+        k_pad = (K + GEMM_K_PAD - 1) // GEMM_K_PAD * GEMM_K_PAD
+        for bi, bits in enumerate(BIT_POOL):
+            name = 'int%d' % bits
+            w2 = w * cs_list[bi].reshape((1, -1))
+            s_w = _need_pot('%d.%s weight scale' % (layer, name), dic_list[bi][name]).reshape(-1)
+            s_x = _need_pot('%d act scale' % layer, s_x_list[bi]).reshape(-1)
+            lo, hi = BOUNDS[bits]
+            wp = torch.zeros(n_pad, k_pad, dtype=torch.int8)
+            wp[:N, :K] = torch.clamp(torch.round(w2 / s_w.reshape(-1, 1)), lo, hi).to(torch.int8)
+            cs_col = torch.zeros(n_pad)
+            cs_col[:N] = (s_x * s_w).expand(N)
+            bp = torch.zeros(n_pad)
+            bp[:N] = bias
+            lin = E.Linear(E.ptr(self._dev(wp, torch.int8)), E.ptr(self._dev(cs_col)), E.ptr(self._dev(bp)))
+            E.check(L.p2v_plan_set_linear(self._handle, layer, bits, C.byref(lin)))
+
+    # ---------------------------------------------------------------------------------------------
+    def workspace(self, batch):
+        if self._ws is None or self._ws_batch < batch:
+            n = E.lib().p2v_workspace_bytes(self._handle, batch)
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws_batch = batch
+        return self._ws
+
+    def forward(self, images, bit_config, stop_after=-1, out=None):
+        """images: fp32 [B,C,H,W] on the plan's device -> fp32 logits [B, classes] (int8 grid * act_out scale)."""
+        a = self.arch
+        if images.dim() != 4 or images.shape[2] != a['img_size'] or images.shape[3] != a['img_size']:
+            raise AssertionError("Input image size (%d*%d) doesn't match model (%d*%d)." % (
+                images.shape[2], images.shape[3], a['img_size'], a['img_size']))      # layers_quant.py:437-439
+        if images.shape[1] != self.in_chans:
+            raise AssertionError('expected %d input channels' % self.in_chans)
+        if not images.is_cuda:
+            raise RuntimeError('the quantized forward runs on the HIP engine only: move the input to the GPU')
+        if bit_config is None:
+            raise ValueError('None is not in list')        # bit_pool.index(None), vit_fquant.py:282
+        images = images.contiguous().float()
+        B = images.shape[0]
+        cfg = (C.c_int8 * len(bit_config))(*[int(b) if -128 <= int(b) <= 127 else 127 for b in bit_config])
+        ws = self.workspace(B)
+        if out is None:
+            out = torch.empty(B, a['num_classes'], dtype=torch.float32, device=self.device)
+        E.check(E.lib().p2v_forward(self._handle, E.ptr(images), B, cfg, len(bit_config), E.ptr(out), E.ptr(ws),
+                                    ws.numel(), stop_after, E.stream_ptr()))
+        return out
+
+    def view(self, batch, name, rows, cols):
+        """int8 view of a workspace activation buffer (parity tests)."""
+        off = E.lib().p2v_workspace_view(self._handle, batch, name.encode())
+        if off < 0:
+            raise KeyError(name)
+        return self._ws[off: off + rows * cols].view(torch.int8).reshape(rows, cols)
+
+    def __del__(self):
+        try:
+            if self._handle:
+                E.lib().p2v_plan_destroy(self._handle)
+                self._handle = C.c_void_p()
+        except Exception:
+            pass

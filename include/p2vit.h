@@ -1,0 +1,204 @@
+/*
+ * p2vit.h -- C ABI of the MI355X-native PoT-PTQ quantized ViT forward engine (libp2vit_hip.so).
+ *
+ * Drop-in boundary.  The reference (LeSN-Lab/diff-ViT) has no native code: its boundary is the Python
+ * nn.Module surface of models/ptq/layers.py plus VisionTransformer.forward (models/vit_fquant.py:780).
+ * This header is what a ctypes/cffi binding inside that surface calls when `.quant` is on; every entry
+ * point names the reference function(s) it replaces.  Signatures carry only PODs, device pointers and a
+ * hipStream_t (passed as void*): no torch types.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a device (HBM) pointer borrowed for the duration of the call (plan
+ *     setters: for the lifetime of the plan); the library never allocates or frees device memory and
+ *     never synchronises; work is enqueued on `stream`.
+ *   - return value: 0 = ok, negative = error (P2V_E_*); p2v_last_error() gives the message of the last
+ *     failing call on the calling thread.  The Python shim maps P2V_E_BITS -> ValueError/KeyError (as
+ *     bit_pool.index / BIT_TYPE_DICT lookups do, vit_fquant.py:282, layers.py:174), P2V_E_SHAPE ->
+ *     AssertionError (layers_quant.py:437), P2V_E_UNSUPPORTED -> NotImplementedError (quantizer/base.py:28).
+ *   - activations between kernels are int8 codes, row-major [rows][channels]; "rows" = batch*tokens.
+ *   - all scales named *_pot are exact powers of two (the reference's PoT observers, minmax.py:247-251);
+ *     per-channel PTF scales (ptf.py:51,133) are arbitrary fp32 and are divided by, as the reference does.
+ */
+#ifndef P2VIT_H
+#define P2VIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2V_ABI_VERSION 1
+
+enum {
+  P2V_OK = 0,
+  P2V_E_ARG = -1,         /* null pointer / bad size                                  */
+  P2V_E_BITS = -2,        /* bit_config entry not in {4,8} or wrong length             */
+  P2V_E_SHAPE = -3,       /* image / tensor shape does not match the plan              */
+  P2V_E_UNSUPPORTED = -4, /* configuration the kernels are not instantiated for        */
+  P2V_E_WORKSPACE = -5,   /* workspace too small                                       */
+  P2V_E_LAUNCH = -6,      /* hipLaunch failure (message carries hipGetErrorString)     */
+  P2V_E_STATE = -7        /* plan incomplete (a setter was not called)                 */
+};
+
+/* GEMM epilogues: what follows F.linear / F.conv2d in the reference graph. */
+enum {
+  P2V_EPI_REQUANT = 0, /* QLinear -> QAct (PoT): attn.qkv->qact1 (vit_fquant.py:293,307)                      */
+  P2V_EPI_GELU = 1,    /* QLinear -> nn.GELU -> QAct (PoT): mlp.fc1->act->qact1 (layers_quant.py:316,331-333) */
+  P2V_EPI_RESID = 2,   /* QLinear -> QAct(PTF) -> + residual -> QAct(PTF): proj->qact3->+x->Block.qact2
+                          (vit_fquant.py:334-338,431) and fc2->qact2->+x->Block.qact4 (layers_quant.py:342-346,
+                          vit_fquant.py:468)                                                                   */
+  P2V_EPI_EMBED = 3,   /* QConv2d -> PatchEmbed.qact -> qact_embed -> + qact_pos(pos) -> qact1(PTF)
+                          (layers_quant.py:467-491, vit_fquant.py:715-733)                                     */
+  P2V_EPI_HEAD = 4     /* head -> act_out, fp32 logits on the int8 grid (vit_fquant.py:792-796)                */
+};
+
+typedef struct p2v_model_desc {
+  int32_t abi_version; /* P2V_ABI_VERSION */
+  int32_t img_size, patch_size, in_chans;
+  int32_t embed_dim, depth, num_heads, mlp_hidden, num_classes;
+} p2v_model_desc;
+
+/* One fake-quantised weight matrix for one bit width (QLinear/QConv2d.forward, layers.py:82-88,173-178;
+ * UniformQuantizer.quant, uniform.py:50-88).  Codes are stored one per byte ([-8,7] for 4-bit), row
+ * major [n_pad][k_pad], n_pad = round_up(N,128), k_pad = round_up(K,64), zero padded.
+ * colscale[n] = s_x * s_w[n]  (activation scale times per-tensor (int8) or per-out-channel (int4) weight
+ * scale; both powers of two, so the product is exact).  bias is the un-quantised fp32 bias. */
+typedef struct p2v_linear {
+  const int8_t* w_codes; /* dev */
+  const float* colscale; /* dev [n_pad] */
+  const float* bias;     /* dev [n_pad] */
+} p2v_linear;
+
+/* QIntLayerNorm.forward mode 'int' (layers.py:255-289) fused with the division by the SmoothQuant
+ * channel scale and the QAct that follows it (vit_fquant.py:284-289, layers_quant.py:305-311).
+ *   x_q = code * mask[c];  mask[c] = round(in_scale[c] / s1), s1 = min_c in_scale[c]
+ *   out = clamp(rne(LN_int(x_q) * post_mul[c]), -128, 127)
+ * inv_out[c] = 1 / (out_quantizer.scale * out_quantizer_scale[c])  (power of two)
+ * post_mul[c] = out_scale[c] / next_channel_scale[c] / next_act_scale  (power of two). */
+typedef struct p2v_ln {
+  float s1;
+  const float* mask;     /* dev [C] */
+  const float* gamma;    /* dev [C] */
+  const float* beta;     /* dev [C] */
+  const float* inv_out;  /* dev [C] */
+  const float* post_mul; /* dev [C] */
+} p2v_ln;
+
+/* (q @ k^T) * scale -> qact_attn1 -> QIntSoftmax (log-int-softmax, uint4) -> @ v -> qact2
+ * (vit_fquant.py:309-326, layers.py:323-376). */
+typedef struct p2v_attn {
+  float s_qkv_sq;   /* s_q1^2                                      */
+  float qk_scale;   /* head_dim^-0.5 (vit_fquant.py:74)            */
+  float inv_s_attn; /* 1 / qact_attn1 scale (pot)                  */
+  float av_mul;     /* s_q1 / qact2 scale (pot)                    */
+  int32_t x0_int, b_int, c_int; /* I-BERT exp polynomial constants (layers.py:334-351) for sf = qact_attn1 scale */
+} p2v_attn;
+
+/* Epilogue parameters; which members are read depends on the epilogue kind. */
+typedef struct p2v_epilogue {
+  float inv_s_out;       /* REQUANT/GELU/HEAD: 1/scale of the following QAct (pot)           */
+  float s_out;           /* HEAD: act_out scale                                               */
+  const float* s_mid;    /* dev [N] RESID: PTF scale of qact3 / mlp.qact2                    */
+  const float* s_res;    /* dev [N] RESID: scale of the residual-stream codes being added     */
+  const float* s_next;   /* dev [N] RESID/EMBED: PTF scale of the QAct that ends the stage    */
+  const int8_t* residual;/* dev [M][N] RESID: residual-stream codes (may alias the output)    */
+  /* EMBED only */
+  float inv_s_pe;        /* 1 / PatchEmbed.qact scale                                         */
+  float pe_to_embed;     /* PatchEmbed.qact scale / qact_embed scale                          */
+  float s_embed;         /* qact_embed scale                                                  */
+  const float* pos_deq;  /* dev [tokens][N]  qact_pos(pos_embed), dequantised                 */
+  int32_t patches;       /* patches per image; output row = b*(patches+1) + 1 + p             */
+} p2v_epilogue;
+
+typedef struct p2v_plan p2v_plan;
+
+/* ---- whole-model entry points: VisionTransformer.forward in quant state (vit_fquant.py:700-799) ---- */
+int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out);
+void p2v_plan_destroy(p2v_plan* plan);
+
+/* layer index follows the reference's bit_config order (vit_fquant.py:710-711,748,789):
+ * 0 = patch embed, 1+4*i+{0,1,2,3} = block i {qkv, proj, fc1, fc2}, 4*depth+1 = head.  bits in {4,8}. */
+int p2v_plan_set_linear(p2v_plan* plan, int layer, int bits, const p2v_linear* lin);
+
+/* qact_input scale; embed epilogue constants (one set per patch-embed bit width index 0:4-bit 1:8-bit is not
+ * needed: activation scales do not depend on the weight bits); cls row codes [D] after qact1. */
+int p2v_plan_set_embed(p2v_plan* plan, float inv_s_input, const p2v_epilogue* embed_epi,
+                       const int8_t* cls_row_codes /* dev [D] */);
+
+/* per block, per bit-pool index (0: 4-bit, 1: 8-bit) of qkv (for ln1/attn side) and of fc1 (for ln2 side):
+ * the reference keeps best_scale/best_act_scale per bit (vit_fquant.py:282-292, layers_quant.py:305-313). */
+typedef struct p2v_block {
+  p2v_ln ln1[2];            /* indexed by bit-pool index of qkv */
+  float inv_s_qkv[2];       /* 1/attn.qact1 scale (same for both, kept per index for symmetry) */
+  p2v_attn attn;
+  p2v_epilogue proj_epi;    /* RESID */
+  p2v_ln ln2[2][2];         /* [bit index of qkv (attn.channel_scale quirk, vit_fquant.py:464)][bit index of fc1] */
+  float inv_s_fc1;          /* 1/mlp.qact1 scale */
+  p2v_epilogue fc2_epi;     /* RESID */
+} p2v_block;
+int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk);
+
+int p2v_plan_set_head(p2v_plan* plan, const p2v_ln* final_ln, float inv_s_out, float s_out);
+
+size_t p2v_workspace_bytes(const p2v_plan* plan, int batch);
+
+/* images: dev fp32 [batch][in_chans][img][img];  bit_config: HOST int8 [n_cfg], n_cfg = 4*depth+2;
+ * logits: dev fp32 [batch][num_classes].  stop_after < 0 runs everything; otherwise execution stops after
+ * that many kernel launches (parity tests read the workspace buffers, see p2v_workspace_view). */
+int p2v_forward(p2v_plan* plan, const float* images, int batch, const int8_t* bit_config, int n_cfg,
+                float* logits, void* workspace, size_t workspace_bytes, int stop_after, void* stream);
+
+/* byte offsets of the named activation buffers inside the workspace for `batch` ("patches", "x", "ln",
+ * "qkv", "att", "hid", "cls"); returns <0 for unknown names. */
+long long p2v_workspace_view(const p2v_plan* plan, int batch, const char* name);
+
+/* ---- per-operator entry points (unit parity, and the module-level surface) --------------------------- */
+
+/* QAct(qact_input) + im2col for the k=stride=patch QConv2d (vit_fquant.py:705-706, layers.py:55-88):
+ * out[b*gh*gw + py*gw + px][c*P*P + i*P + j] = clamp(rne(img[b][c][py*P+i][px*P+j] * inv_s), -128, 127);
+ * columns [C*P*P, k_pad) are zeroed. */
+int p2v_quantize_patchify(const float* img, int batch, int chans, int height, int width, int patch,
+                          float inv_s, int8_t* out, int k_pad, void* stream);
+
+/* out = epilogue(A[M][K] . W[N][K]^T): int8 MFMA (v_mfma_i32_32x32x32_i8), fp32 epilogue in the
+ * reference's operation order.  lda/ldo in elements.  `out` is int8 [M][ldo] except HEAD (fp32 [M][ldo]);
+ * when out_codes != NULL the HEAD epilogue also writes the int8 logit codes there ([M][ldo]). */
+int p2v_gemm_i8(int epilogue_kind, const int8_t* A, int lda, int M, int K, int N, const p2v_linear* lin,
+                const p2v_epilogue* epi, void* out, int ldo, int8_t* out_codes, void* stream);
+
+/* rows x C int8 -> rows x C int8; row r of the input starts at x + r*row_stride (lets the final norm
+ * touch only the cls rows, vit_fquant.py:766-767). */
+int p2v_int_layernorm(const int8_t* x, long long row_stride, int rows, int C, const p2v_ln* ln,
+                      int8_t* out, long long out_stride, void* stream);
+
+/* fused attention core on the int8 qkv tensor [batch*tokens][3*heads*head_dim] (layout of
+ * qkv.reshape(B,N,3,H,hd), vit_fquant.py:309-315); out int8 [batch*tokens][heads*head_dim].
+ * probs_k (optional, dev int8 [batch][heads][tokens][tokens]) receives the log2 softmax exponents
+ * (16 = zero) for parity tests. */
+int p2v_lis_attention(const int8_t* qkv, int batch, int tokens, int heads, int head_dim, const p2v_attn* at,
+                      int8_t* out, int8_t* probs_k, void* stream);
+
+/* UniformQuantizer.forward on an fp32 tensor (uniform.py:50-127, base.py:42-45): fake-quant in place of
+ * the eager round/clamp chain.  scale has `n_scale` entries (1 = layer-wise) applied along the channel
+ * dimension: element i uses scale[(i / inner) % n_scale].  codes (optional) receives the int8 codes. */
+int p2v_fake_quant_f32(const float* x, long long n, const float* scale, int n_scale, long long inner,
+                       int lo, int hi, float* out, int8_t* codes, void* stream);
+
+/* correctly-rounded fp32 GELU followed by PoT quantisation (checks the fast path of the GELU epilogue
+ * against its own fp64 slow path; flags[0] counts slow-path lanes). */
+int p2v_gelu_quant_f32(const float* y, long long n, float inv_s, int8_t* codes, unsigned long long* flags,
+                       int force_slow, void* stream);
+
+/* max |fast GELU - fp64 GELU| over `count` consecutive fp32 bit patterns starting at first_bits; *max_err
+ * (dev, fp32 bits compared as unsigned) must be zeroed by the caller.  Bound check for the epilogue. */
+int p2v_gelu_err_sweep(unsigned first_bits, unsigned count, float* max_err, void* stream);
+
+const char* p2v_last_error(void);
+int p2v_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2VIT_H */

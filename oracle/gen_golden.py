@@ -106,7 +106,9 @@ def compare_oracle(tag, orc, x, bit_config, ref_out, ref_taps):
         print('      tap %-34s %d / %d differ' % (k, n, sz))
     if not worst:
         print('      all %d taps bit-equal' % len(ref_taps))
-    return int((dcode > 0).sum())
+    top1 = int((out.argmax(1) == ref_out.argmax(1)).sum())
+    return dict(logit_codes_differ=int((dcode > 0).sum()), max_code_diff=int(dcode.max()), top1_agree=top1,
+                first_divergence=('%s:%d/%d' % worst[0]) if worst else 'none')
 
 
 def gen_model_fixture(name, arch, seed, n_calib, n_eval, store_weights, tap_filter, ref):
@@ -142,10 +144,13 @@ def gen_model_fixture(name, arch, seed, n_calib, n_eval, store_weights, tap_filt
         assert gd2 == [] and fl == list(out['flops'])
         out['logits/' + tag] = o.numpy()
         out['top5/' + tag] = o.topk(min(5, o.shape[1]), 1, True, True)[1].numpy()
-        if tag != 'q4':
+        if tag != 'q4' and (store_weights or tag == 'q8'):
             for k, v in taps.items():
-                out['taps/%s/%s' % (tag, k)] = v.astype(np.int8) if np.abs(v).max() < 128 else v
-        compare_oracle(name + '/' + tag, orc, x_ev, bc, o, taps)
+                if store_weights or v.size <= n_eval * 197 * 384:
+                    out['taps/%s/%s' % (tag, k)] = v.astype(np.int8) if np.abs(v).max() < 128 else v
+        rep = compare_oracle(name + '/' + tag, orc, x_ev, bc, o, taps)
+        for kk, vv in rep.items():
+            out['canon_vs_ref/%s/%s' % (tag, kk)] = np.array(vv)
     # float pass parity of the oracle restatement
     print('  oracle float_forward max|d| = %.3g' % float((orc.float_forward(x_ev) - fp).abs().max()))
     if store_weights:
@@ -264,7 +269,7 @@ def main():
         print('deit_tiny_fp: wrote')
     if what in ('deit_small', 'all'):
         keep = lambda n: n.startswith(('blocks.0.', 'blocks.11.')) or '.' not in n or n.startswith('patch_embed')
-        gen_model_fixture('deit_small', synth.ARCHS['deit_small'], 3, 2, 2, False, keep, ref)
+        gen_model_fixture('deit_small', synth.ARCHS['deit_small'], 3, 2, 4, False, keep, ref)
 
 
 if __name__ == '__main__':

@@ -1,0 +1,47 @@
+"""CPU: the C-ABI library loads and exports every symbol include/p2vit.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'p2vit.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(p2v_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_exported():
+    import diff_vit_amd
+    if not diff_vit_amd.engine.available():
+        pytest.fail('libp2vit_hip.so is not built: run __graft_entry__.build()')
+    lib = ctypes.CDLL(diff_vit_amd.engine.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(lib, n), n
+    assert diff_vit_amd.engine.lib().p2v_abi_version() == diff_vit_amd.engine.P2V_ABI_VERSION
+
+
+def test_error_conventions_without_gpu():
+    """argument validation happens before any HIP call, so it is checkable on CPU."""
+    import diff_vit_amd
+    E = diff_vit_amd.engine
+    L = E.lib()
+    h = ctypes.c_void_p()
+    bad = E.ModelDesc(E.P2V_ABI_VERSION, 224, 15, 3, 384, 12, 6, 1536, 1000)
+    with pytest.raises(AssertionError):
+        E.check(L.p2v_plan_create(ctypes.byref(bad), ctypes.byref(h)))
+    ok = E.ModelDesc(E.P2V_ABI_VERSION, 224, 16, 3, 384, 12, 6, 1536, 1000)
+    E.check(L.p2v_plan_create(ctypes.byref(ok), ctypes.byref(h)))
+    assert L.p2v_workspace_bytes(h, 256) > 200e6
+    lin = E.Linear(None, None, None)
+    with pytest.raises(ValueError):
+        E.check(L.p2v_plan_set_linear(h, 0, 6, ctypes.byref(lin)))     # 6-bit: not in bit_pool
+    cfg = (ctypes.c_int8 * 50)(*([8] * 50))
+    rc = L.p2v_forward(h, ctypes.c_void_p(1), 1, cfg, 49, ctypes.c_void_p(1), ctypes.c_void_p(1), 0, -1, None)
+    assert rc == E.E_BITS                                                 # wrong bit_config length
+    L.p2v_plan_destroy(h)

@@ -1,0 +1,267 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the oracle and the reference golden vectors.
+Bit-exact: every comparison below is integer equality."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_calib, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dva():
+    import diff_vit_amd
+    assert torch.cuda.is_available(), 'GPU tests need the MI355X box'
+    diff_vit_amd.engine.lib()
+    return diff_vit_amd
+
+
+def _bits(g, tag, L):
+    return {'q8': [8] * L, 'q4': [4] * L, 'qmix': [int(b) for b in g['bit_qmix']]}[tag]
+
+
+# --------------------------------------------------------------------------------------------------
+# whole model, micro-ViT: logits AND every intermediate buffer equal the real reference's
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('tag', ('q8', 'q4', 'qmix'))
+def test_micro_model_vs_reference_golden(dva, micro, tag):
+    g, arch = micro['g'], micro['arch']
+    plan = dva.FrozenPlan(arch, micro['sd'], micro['calib'])
+    x = micro['x_ev'].cuda()
+    B, L, D, depth = x.shape[0], 4 * arch['depth'] + 2, arch['embed_dim'], arch['depth']
+    T = plan.tokens
+    bits = _bits(g, tag, L)
+    out = plan.forward(x, bits)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), g['logits/' + tag])
+    assert np.array_equal(out.cpu().topk(5, 1, True, True)[1].numpy(), g['top5/' + tag])
+    if tag == 'q4':
+        return
+    # launch order (p2vit_capi.cpp): 0 patchify, 1 embed, 2 cls | per block: ln1 qkv attn proj ln2 fc1 fc2
+    stages = [(3, 'x', T, D, 'qact1')]
+    for i in range(depth):
+        p = 'blocks.%d.' % i
+        b = 3 + 7 * i
+        stages += [(b + 1, 'ln', T, D, p + 'attn.qact0'), (b + 2, 'qkv', T, 3 * D, p + 'attn.qact1'),
+                   (b + 3, 'att', T, D, p + 'attn.qact2'), (b + 4, 'x', T, D, p + 'qact2'),
+                   (b + 5, 'ln', T, D, p + 'mlp.qact0'), (b + 6, 'hid', T, plan.hidden, p + 'mlp.qact1'),
+                   (b + 7, 'x', T, D, p + 'qact4')]
+    stages.append((3 + 7 * depth + 1, 'cls', 1, D, 'qact2'))
+    for stop, buf, rows, cols, name in stages:
+        plan.forward(x, bits, stop_after=stop)
+        torch.cuda.synchronize()
+        got = plan.view(B, buf, B * rows, cols).cpu().numpy()
+        ref = g['taps/%s/%s' % (tag, name)].reshape(B * rows, cols)
+        assert np.array_equal(got.astype(np.int64), ref.astype(np.int64)), (name, int((got != ref).sum()))
+
+
+def test_bit_config_and_shape_errors(dva, micro):
+    plan = dva.FrozenPlan(micro['arch'], micro['sd'], micro['calib'])
+    x = micro['x_ev'].cuda()
+    with pytest.raises(ValueError):
+        plan.forward(x, [8] * 9 + [6])
+    with pytest.raises(ValueError):
+        plan.forward(x, [8] * 9)
+    with pytest.raises(ValueError):
+        plan.forward(x, None)
+    with pytest.raises(AssertionError):
+        plan.forward(torch.zeros(1, 3, 40, 40, device='cuda'), [8] * 10)
+    with pytest.raises(RuntimeError):
+        plan.forward(micro['x_ev'], [8] * 10)          # CPU tensor: no fallback
+
+
+# --------------------------------------------------------------------------------------------------
+# whole model, DeiT-S (BASELINE config 2 shape) vs the oracle with the reference's calibration state
+# --------------------------------------------------------------------------------------------------
+def test_deit_small_vs_oracle_and_golden(dva, oracle, synth):
+    g = load_golden('deit_small')
+    arch = synth.ARCHS['deit_small']
+    seed = int(g['seed'])
+    sd = synth.vit_state_dict(arch, seed)
+    calib = golden_calib(g, oracle)
+    plan = dva.FrozenPlan(arch, sd, calib)
+    x = synth.images(seed, int(g['n_eval']), 224, offset=1000)
+    orc = oracle.OracleViT(arch, sd)
+    orc.calib = calib
+    # [4]*50: equal to the REAL reference bit for bit
+    out4 = plan.forward(x.cuda(), [4] * 50).cpu()
+    assert np.array_equal(out4.numpy(), g['logits/q4'])
+    for tag in ('q8', 'qmix'):
+        bits = _bits(g, tag, 50)
+        taps = {}
+        ref = orc.quant_forward(x, bits, taps)
+        out = plan.forward(x.cuda(), bits).cpu()
+        assert np.array_equal(out.numpy(), ref.numpy()), tag
+        assert np.array_equal(out.argmax(1).numpy(), g['logits/' + tag].argmax(1))      # top-1 == reference
+        B, T, D = x.shape[0], 197, 384
+        for stop, buf, cols, name in ((3, 'x', D, 'qact1'), (4, 'ln', D, 'blocks.0.attn.qact0'),
+                                      (5, 'qkv', 3 * D, 'blocks.0.attn.qact1'), (6, 'att', D, 'blocks.0.attn.qact2'),
+                                      (7, 'x', D, 'blocks.0.qact2'), (9, 'hid', 4 * D, 'blocks.0.mlp.qact1'),
+                                      (10, 'x', D, 'blocks.0.qact4'), (3 + 7 * 12, 'x', D, 'blocks.11.qact4')):
+            plan.forward(x.cuda(), bits, stop_after=stop)
+            got = plan.view(B, buf, B * T, cols).cpu().numpy().astype(np.int64)
+            assert np.array_equal(got, taps[name].reshape(B * T, cols).numpy().astype(np.int64)), (tag, name)
+
+
+def test_batch_independence_and_ragged_batch(dva, micro):
+    """images are independent: a ragged batch (B=5, rows not a multiple of any tile) equals per-image runs."""
+    plan = dva.FrozenPlan(micro['arch'], micro['sd'], micro['calib'])
+    x = micro['x_ev'][:5].cuda()
+    full = plan.forward(x, [8] * 10).cpu()
+    for i in range(5):
+        one = plan.forward(x[i:i + 1], [8] * 10).cpu()
+        assert torch.equal(one[0], full[i])
+
+
+# --------------------------------------------------------------------------------------------------
+# per-operator entry points
+# --------------------------------------------------------------------------------------------------
+def test_quantize_patchify(dva):
+    E = dva.engine
+    x = dva.synth.images(5, 3, 32).cuda() * 3
+    inv_s = 2.0 ** 4
+    out = torch.full((3 * 16, 192), 99, dtype=torch.int8, device='cuda')
+    E.check(E.lib().p2v_quantize_patchify(E.ptr(x), 3, 3, 32, 32, 8, inv_s, E.ptr(out), 192, E.stream_ptr()))
+    q = torch.clamp(torch.round(x.cpu() * inv_s), -128, 127)
+    ref = torch.nn.functional.unfold(q, 8, stride=8).transpose(1, 2).reshape(-1, 192)
+    assert torch.equal(out.cpu().float(), ref)
+
+
+def _rand_codes(synth, seed, name, shape, std=40.0):
+    return torch.clamp(torch.round(synth.normal(seed, name, shape, std)), -128, 127)
+
+
+@pytest.mark.parametrize('M,K,N', [(300, 64, 192), (394, 384, 1152), (130, 1536, 384)])
+def test_gemm_requant_and_gelu(dva, oracle, M, K, N):
+    E, S = dva.engine, dva.synth
+    x = _rand_codes(S, 1, 'gx', (M, K))
+    w = _rand_codes(S, 1, 'gw', (N, K), 30.0)
+    bias = S.normal(1, 'gb', (N,), 0.4)
+    s_x, s_w = 2.0 ** -5, torch.full((N,), 2.0 ** -7)
+    s_w[::3] = 2.0 ** -6                                     # per-out-channel scales (int4 style)
+    n_pad = (N + 127) // 128 * 128
+    wp = torch.zeros(n_pad, K, dtype=torch.int8); wp[:N] = w.to(torch.int8)
+    cs = torch.zeros(n_pad); cs[:N] = s_x * s_w
+    bp = torch.zeros(n_pad); bp[:N] = bias
+    dev = [t.cuda() for t in (x.to(torch.int8), wp, cs, bp)]
+    lin = E.Linear(E.ptr(dev[1]), E.ptr(dev[2]), E.ptr(dev[3]))
+    y = oracle.qgemm(x, torch.tensor(s_x), w, s_w, bias)
+    for kind, s_out in ((E.EPI_REQUANT, 2.0 ** -3), (E.EPI_GELU, 2.0 ** -5)):
+        epi = E.Epilogue(); epi.inv_s_out = 1.0 / s_out
+        out = torch.zeros(M, N, dtype=torch.int8, device='cuda')
+        E.check(E.lib().p2v_gemm_i8(kind, E.ptr(dev[0]), K, M, K, N, C.byref(lin), C.byref(epi), E.ptr(out), N, None, E.stream_ptr()))
+        v = oracle.gelu_rn(y) if kind == E.EPI_GELU else y
+        ref = torch.clamp(torch.round(v / s_out), -128, 127)
+        got = out.cpu().float()
+        assert torch.equal(got, ref), (kind, int((got != ref).sum()))
+        assert ref.abs().max() == 128 or ref.max() == 127          # clamps exercised
+
+
+def test_gemm_residual_epilogue(dva, oracle):
+    E, S = dva.engine, dva.synth
+    M, K, N = 333, 256, 128
+    x = _rand_codes(S, 2, 'rx', (M, K)); w = _rand_codes(S, 2, 'rw', (N, K), 30.0)
+    bias = S.normal(2, 'rb', (N,), 0.4)
+    res = _rand_codes(S, 2, 'rr', (M, N), 50.0)
+    ptf = lambda nm, base: base * 2.0 ** torch.floor(S.uniform(2, nm, (N,), 0, 3.99))
+    s_mid, s_res, s_next = ptf('m', 0.0131), ptf('r', 0.0173), ptf('n', 0.0209)
+    s_x, s_w = 2.0 ** -5, 2.0 ** -8
+    y = oracle.qgemm(x, torch.tensor(s_x), w, torch.full((N,), s_w), bias)
+    q3 = torch.clamp(torch.round(y / s_mid), -128, 127)
+    ref = torch.clamp(torch.round((res * s_res + q3 * s_mid) / s_next), -128, 127)
+    dev = dict(x=x.to(torch.int8).cuda(), w=w.to(torch.int8).cuda(), cs=torch.full((N,), s_x * s_w).cuda(), b=bias.cuda(),
+               sm=s_mid.cuda(), sr=s_res.cuda(), sn=s_next.cuda(), xres=res.to(torch.int8).cuda())
+    lin = E.Linear(E.ptr(dev['w']), E.ptr(dev['cs']), E.ptr(dev['b']))
+    epi = E.Epilogue(); epi.s_mid = E.ptr(dev['sm']); epi.s_res = E.ptr(dev['sr']); epi.s_next = E.ptr(dev['sn'])
+    epi.residual = E.ptr(dev['xres'])
+    # in place, as p2v_forward uses it
+    E.check(E.lib().p2v_gemm_i8(E.EPI_RESID, E.ptr(dev['x']), K, M, K, N, C.byref(lin), C.byref(epi), E.ptr(dev['xres']), N, None, E.stream_ptr()))
+    assert torch.equal(dev['xres'].cpu().float(), ref)
+
+
+@pytest.mark.parametrize('C_,rows', [(64, 37), (192, 100), (384, 777), (768, 65), (1024, 9)])
+def test_int_layernorm(dva, oracle, C_, rows):
+    E, S = dva.engine, dva.synth
+    codes = _rand_codes(S, 3, 'lx', (1, rows, C_), 35.0)
+    codes[0, 0] = torch.round(codes[0, 0] * 0.03)
+    in_scale = 0.0123 * 2.0 ** torch.floor(S.uniform(3, 'lm', (C_,), 0, 3.99))
+    gamma = S.uniform(3, 'lg', (C_,), -1.5, 1.5); beta = S.normal(3, 'lb', (C_,), 0.3)
+    cs = 2.0 ** torch.floor(S.uniform(3, 'lc', (C_,), -2, 2.99))
+    cs_next = 2.0 ** torch.floor(S.uniform(3, 'ld', (C_,), -2, 2.99))
+    s_a = 2.0 ** -4
+    out_scale = s_a * cs
+    ln = oracle.int_layernorm(codes * in_scale.reshape(1, 1, -1), in_scale, gamma, beta, out_scale)
+    ref = torch.clamp(torch.round((ln * out_scale.reshape(1, 1, -1)) / cs_next.reshape(1, 1, -1) / s_a), -128, 127)[0]
+    s1 = in_scale.min()
+    dev = [t.contiguous().cuda() for t in (codes[0].to(torch.int8), torch.round(in_scale / s1), gamma, beta, 1.0 / out_scale,
+                                           out_scale / cs_next / s_a)]
+    lnp = E.Ln(float(s1), *[E.ptr(t) for t in dev[1:]])
+    out = torch.zeros(rows, C_, dtype=torch.int8, device='cuda')
+    E.check(E.lib().p2v_int_layernorm(E.ptr(dev[0]), C_, rows, C_, C.byref(lnp), E.ptr(out), C_, E.stream_ptr()))
+    got = out.cpu().float()
+    assert torch.equal(got, ref), int((got != ref).sum())
+    assert ln.abs().max() > 127
+
+
+@pytest.mark.parametrize('B,N,H,hd,e_at', [(2, 17, 2, 32, 4), (3, 49, 4, 32, 5), (2, 197, 3, 64, 4), (1, 197, 6, 64, 6), (2, 50, 2, 64, 3)])
+def test_lis_attention(dva, oracle, B, N, H, hd, e_at):
+    E, S = dva.engine, dva.synth
+    D = H * hd
+    qkv = _rand_codes(S, 4, 'aq%d' % N, (B, N, 3 * D), 30.0)
+    qkv[0, 0, :D] = 127                      # a saturating score row
+    qkv[0, 1, :D] = 0                        # an all-equal score row
+    s_q1, s_at, s_a2 = 2.0 ** -4, 2.0 ** -e_at, 2.0 ** -3
+    t = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    acc = t[0] @ t[1].transpose(-2, -1)
+    scale = float(np.float32(hd ** -0.5))
+    sc = torch.clamp(torch.round(((acc * (s_q1 * s_q1)) * scale) / s_at), -128, 127)
+    k = oracle.lis_int(sc, torch.tensor([s_at]))
+    o = (oracle.lis_probs(k) @ (t[2] * s_q1)).transpose(1, 2).reshape(B, N, D)
+    ref = torch.clamp(torch.round(o / s_a2), -128, 127)
+    x0, bb, cc = oracle.lis_consts(torch.tensor([s_at]))
+    at = E.Attn(s_q1 * s_q1, scale, 1.0 / s_at, s_q1 / s_a2, x0, bb, cc)
+    dq = qkv.to(torch.int8).cuda()
+    out = torch.zeros(B * N, D, dtype=torch.int8, device='cuda')
+    pk = torch.full((B, H, N, N), -1, dtype=torch.int8, device='cuda')
+    E.check(E.lib().p2v_lis_attention(E.ptr(dq), B, N, H, hd, C.byref(at), E.ptr(out), E.ptr(pk), E.stream_ptr()))
+    assert torch.equal(pk.cpu().long(), k), int((pk.cpu().long() != k).sum())
+    got = out.cpu().float().reshape(B, N, D)
+    assert torch.equal(got, ref), int((got != ref).sum())
+    assert (k == 16).any() and (k == 0).any()
+
+
+def test_fake_quant(dva, oracle):
+    E = dva.engine
+    g = load_golden('kat_ops')
+    x, s = torch.from_numpy(g['uq/x']).cuda(), torch.from_numpy(g['uq/scale']).cuda()
+    for bt in ('int8', 'int4', 'uint4'):
+        lo, hi = oracle.BITS[bt]
+        out = torch.empty_like(x)
+        E.check(E.lib().p2v_fake_quant_f32(E.ptr(x), x.numel(), E.ptr(s), 16, 1, lo, hi, E.ptr(out), None, E.stream_ptr()))
+        assert np.array_equal(out.cpu().numpy(), g['uq/%s/out' % bt]), bt
+
+
+def test_gelu_fast_path_bound_and_exactness(dva, oracle):
+    """(1) sweep EVERY fp32 in +-[2^-20, 32): |fast - fp64| must stay below GELU_EPS/2;  (2) fast+fallback
+    codes == forced-slow codes == oracle on a dense sample."""
+    E = dva.engine
+    err = torch.zeros(1, dtype=torch.float32, device='cuda')
+    lo, hi = np.float32(2.0 ** -20).view(np.uint32), np.float32(32.0).view(np.uint32)
+    for sign in (0, 0x80000000):
+        E.check(E.lib().p2v_gelu_err_sweep(int(lo) | sign, int(hi - lo), E.ptr(err), E.stream_ptr()))
+    torch.cuda.synchronize()
+    assert float(err.item()) < 2.0e-6, float(err.item())
+    y = torch.cat([dva.synth.normal(9, 'gelu', (1 << 22,), 2.5), torch.linspace(-9, 9, 1 << 20)]).cuda()
+    for e in (3, 5, 7):
+        inv_s = 2.0 ** e
+        fast = torch.empty(y.numel(), dtype=torch.int8, device='cuda'); slow = torch.empty_like(fast)
+        flags = torch.zeros(1, dtype=torch.int64, device='cuda')
+        E.check(E.lib().p2v_gelu_quant_f32(E.ptr(y), y.numel(), inv_s, E.ptr(fast), E.ptr(flags), 0, E.stream_ptr()))
+        E.check(E.lib().p2v_gelu_quant_f32(E.ptr(y), y.numel(), inv_s, E.ptr(slow), None, 1, E.stream_ptr()))
+        ref = torch.clamp(torch.round(oracle.gelu_rn(y.cpu()) * inv_s), -128, 127)
+        assert torch.equal(fast, slow)
+        assert torch.equal(slow.cpu().float(), ref), int((slow.cpu().float() != ref).sum())
+        assert 0 < int(flags.item()) < y.numel() * 0.01
