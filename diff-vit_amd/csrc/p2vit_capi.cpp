@@ -167,8 +167,13 @@ static int run_gemm(int epi, const int8_t* A, int lda, int M, int K, int N, cons
   return launch_rc(p2v_launch_gemm(epi, g, st), "gemm_i8");
 }
 
-int p2v_forward(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
-                size_t workspace_bytes, int stop_after, void* stream) {
+struct Prof {
+  std::vector<hipEvent_t> ev;   // ev[i] recorded before launch i; one more after the last
+  std::vector<int> kind;        // P2V_K_* of launch i
+};
+
+static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
+                        size_t workspace_bytes, int stop_after, void* stream, Prof* prof) {
   if (!p || !images || !bit_config || !logits || !workspace) return fail(P2V_E_ARG, "p2v_forward: null argument");
   if (batch <= 0) return fail(P2V_E_SHAPE, "batch must be positive");
   if (n_cfg != p->n_layers) return fail(P2V_E_BITS, "bit_config has %d entries, model needs %d", n_cfg, p->n_layers);
@@ -189,22 +194,29 @@ int p2v_forward(p2v_plan* p, const float* images, int batch, const int8_t* bit_c
   const p2v_model_desc& d = p->d;
   const int D = d.embed_dim, T = p->tokens, M = batch * T, Hd = d.mlp_hidden, hd = D / d.num_heads;
   int launched = 0, rc;
-#define STEP(call)                                    \
+#define STEP(kind_, call)                             \
   do {                                                \
     if (stop_after >= 0 && launched >= stop_after) return P2V_OK; \
+    if (prof) {                                       \
+      hipEvent_t e_;                                  \
+      if (hipEventCreate(&e_) != hipSuccess) return fail(P2V_E_LAUNCH, "hipEventCreate failed"); \
+      hipEventRecord(e_, st);                         \
+      prof->ev.push_back(e_);                         \
+      prof->kind.push_back(kind_);                    \
+    }                                                 \
     rc = (call);                                      \
     if (rc) return rc;                                \
     ++launched;                                       \
   } while (0)
 
   // qact_input + PatchEmbed + cls/pos/qact1                                 vit_fquant.py:705-733
-  STEP(launch_rc(p2v_launch_patchify(images, batch, d.in_chans, d.img_size, d.img_size, d.patch_size, p->inv_s_input, bufP,
+  STEP(P2V_K_PATCHIFY, launch_rc(p2v_launch_patchify(images, batch, d.in_chans, d.img_size, d.img_size, d.patch_size, p->inv_s_input, bufP,
                                      p->k_patch_pad, st), "quantize_patchify"));
   {
     const p2v_linear& l = p->lin[bit_index(bit_config[0])][0];
-    STEP(run_gemm(P2V_EPI_EMBED, bufP, p->k_patch_pad, batch * p->patches, p->k_patch_pad, D, l, p->embed_epi, bufX, D, nullptr, st));
+    STEP(P2V_K_GEMM_EMBED, run_gemm(P2V_EPI_EMBED, bufP, p->k_patch_pad, batch * p->patches, p->k_patch_pad, D, l, p->embed_epi, bufX, D, nullptr, st));
   }
-  STEP(launch_rc(p2v_launch_fill_cls(bufX, batch, T, D, p->cls_codes, st), "fill_cls"));
+  STEP(P2V_K_FILL_CLS, launch_rc(p2v_launch_fill_cls(bufX, batch, T, D, p->cls_codes, st), "fill_cls"));
 
   for (int i = 0; i < d.depth; ++i) {
     const p2v_block& b = p->blocks[i];
@@ -212,40 +224,71 @@ int p2v_forward(p2v_plan* p, const float* images, int batch, const int8_t* bit_c
     const int bq = bit_index(bc[0]), bp = bit_index(bc[1]), b1 = bit_index(bc[2]), b2 = bit_index(bc[3]);
     // norm1 -> /channel_scale -> qact0                                     vit_fquant.py:431-434,284-289
     LnArgs ln{bufX, D, M, D, b.ln1[bq], bufLN, D};
-    STEP(launch_rc(p2v_launch_layernorm(ln, st), "int_layernorm"));
+    STEP(P2V_K_LAYERNORM, launch_rc(p2v_launch_layernorm(ln, st), "int_layernorm"));
     // qkv -> qact1                                                          vit_fquant.py:293,307
     p2v_epilogue e{};
     e.inv_s_out = b.inv_s_qkv[bq];
-    STEP(run_gemm(P2V_EPI_REQUANT, bufLN, D, M, D, 3 * D, p->lin[bq][1 + 4 * i], e, bufQKV, 3 * D, nullptr, st));
+    STEP(P2V_K_GEMM_QKV, run_gemm(P2V_EPI_REQUANT, bufLN, D, M, D, 3 * D, p->lin[bq][1 + 4 * i], e, bufQKV, 3 * D, nullptr, st));
     // scores -> qact_attn1 -> log-int-softmax -> @v -> qact2                vit_fquant.py:309-326
     AttnArgs at{bufQKV, batch, T, d.num_heads, b.attn, bufATT, nullptr};
-    STEP(launch_rc(p2v_launch_attention(at, hd, st), "lis_attention"));
+    STEP(P2V_K_ATTENTION, launch_rc(p2v_launch_attention(at, hd, st), "lis_attention"));
     // proj -> qact3 -> + x -> Block.qact2                                   vit_fquant.py:334-338,431
     p2v_epilogue ep = b.proj_epi;
     ep.residual = bufX;
-    STEP(run_gemm(P2V_EPI_RESID, bufATT, D, M, D, D, p->lin[bp][2 + 4 * i], ep, bufX, D, nullptr, st));
+    STEP(P2V_K_GEMM_PROJ, run_gemm(P2V_EPI_RESID, bufATT, D, M, D, D, p->lin[bp][2 + 4 * i], ep, bufX, D, nullptr, st));
     // norm2 (attention's channel scale!) -> /mlp.channel_scale -> mlp.qact0 vit_fquant.py:464, layers_quant.py:305-311
     LnArgs ln2{bufX, D, M, D, b.ln2[bq][b1], bufLN, D};
-    STEP(launch_rc(p2v_launch_layernorm(ln2, st), "int_layernorm"));
+    STEP(P2V_K_LAYERNORM, launch_rc(p2v_launch_layernorm(ln2, st), "int_layernorm"));
     // fc1 -> GELU -> qact1                                                  layers_quant.py:316,331-333
     p2v_epilogue e1{};
     e1.inv_s_out = b.inv_s_fc1;
-    STEP(run_gemm(P2V_EPI_GELU, bufLN, D, M, D, Hd, p->lin[b1][3 + 4 * i], e1, bufHID, Hd, nullptr, st));
+    STEP(P2V_K_GEMM_FC1, run_gemm(P2V_EPI_GELU, bufLN, D, M, D, Hd, p->lin[b1][3 + 4 * i], e1, bufHID, Hd, nullptr, st));
     // fc2 -> qact2 -> + x -> Block.qact4                                    layers_quant.py:342-346, vit_fquant.py:468
     p2v_epilogue e2 = b.fc2_epi;
     e2.residual = bufX;
-    STEP(run_gemm(P2V_EPI_RESID, bufHID, Hd, M, Hd, D, p->lin[b2][4 + 4 * i], e2, bufX, D, nullptr, st));
+    STEP(P2V_K_GEMM_FC2, run_gemm(P2V_EPI_RESID, bufHID, Hd, M, Hd, D, p->lin[b2][4 + 4 * i], e2, bufX, D, nullptr, st));
   }
   // norm over the cls rows only ([:,0]) -> qact2 -> head -> act_out         vit_fquant.py:766-796
   LnArgs lf{bufX, (long long)T * D, batch, D, p->final_ln, bufCLS, D};
-  STEP(launch_rc(p2v_launch_layernorm(lf, st), "int_layernorm"));
+  STEP(P2V_K_LAYERNORM, launch_rc(p2v_launch_layernorm(lf, st), "int_layernorm"));
   p2v_epilogue eh{};
   eh.inv_s_out = p->head_inv_s;
   eh.s_out = p->head_s;
-  STEP(run_gemm(P2V_EPI_HEAD, bufCLS, D, batch, D, d.num_classes, p->lin[bit_index(bit_config[n_cfg - 1])][n_cfg - 1], eh, logits,
+  STEP(P2V_K_GEMM_HEAD, run_gemm(P2V_EPI_HEAD, bufCLS, D, batch, D, d.num_classes, p->lin[bit_index(bit_config[n_cfg - 1])][n_cfg - 1], eh, logits,
                 d.num_classes, nullptr, st));
 #undef STEP
+  if (prof) {
+    hipEvent_t e_;
+    if (hipEventCreate(&e_) != hipSuccess) return fail(P2V_E_LAUNCH, "hipEventCreate failed");
+    hipEventRecord(e_, st);
+    prof->ev.push_back(e_);
+  }
   return P2V_OK;
+}
+
+int p2v_forward(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
+                size_t workspace_bytes, int stop_after, void* stream) {
+  return forward_impl(p, images, batch, bit_config, n_cfg, logits, workspace, workspace_bytes, stop_after, stream, nullptr);
+}
+
+int p2v_forward_profile(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
+                        size_t workspace_bytes, void* stream, float* ms_out, int32_t* kind_out, int max_launches) {
+  if (!ms_out || !kind_out || max_launches <= 0) return fail(P2V_E_ARG, "p2v_forward_profile: null argument");
+  Prof prof;
+  int rc = forward_impl(p, images, batch, bit_config, n_cfg, logits, workspace, workspace_bytes, -1, stream, &prof);
+  int n = 0;
+  if (rc == P2V_OK) {
+    hipEventSynchronize(prof.ev.back());
+    n = (int)prof.kind.size();
+    for (int i = 0; i < n && i < max_launches; ++i) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, prof.ev[i], prof.ev[i + 1]);
+      ms_out[i] = ms;
+      kind_out[i] = prof.kind[i];
+    }
+  }
+  for (hipEvent_t e : prof.ev) hipEventDestroy(e);
+  return rc == P2V_OK ? n : rc;
 }
 
 // ---- per-operator entry points ------------------------------------------------------------------------

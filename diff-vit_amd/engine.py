@@ -14,6 +14,9 @@ P2V_ABI_VERSION = 1
 EPI_REQUANT, EPI_GELU, EPI_RESID, EPI_EMBED, EPI_HEAD = 0, 1, 2, 3, 4
 E_ARG, E_BITS, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH, E_STATE = -1, -2, -3, -4, -5, -6, -7
 
+KERNEL_KINDS = ('patchify', 'gemm_embed', 'fill_cls', 'layernorm', 'gemm_qkv', 'attention', 'gemm_proj', 'gemm_fc1',
+                'gemm_fc2', 'gemm_head')
+
 _f, _i, _p, _ll = C.c_float, C.c_int32, C.c_void_p, C.c_longlong
 
 
@@ -79,6 +82,8 @@ def lib():
     L.p2v_workspace_view.argtypes = [_p, _i, C.c_char_p]
     L.p2v_workspace_view.restype = _ll
     L.p2v_forward.argtypes = [_p, _p, _i, C.POINTER(C.c_int8), _i, _p, _p, C.c_size_t, _i, _p]
+    L.p2v_forward_profile.argtypes = [_p, _p, _i, C.POINTER(C.c_int8), _i, _p, _p, C.c_size_t, _p, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_int32), _i]
     L.p2v_quantize_patchify.argtypes = [_p, _i, _i, _i, _i, _i, _f, _p, _i, _p]
     L.p2v_gemm_i8.argtypes = [_i, _p, _i, _i, _i, _i, C.POINTER(Linear), C.POINTER(Epilogue), _p, _i, _p, _p]
     L.p2v_int_layernorm.argtypes = [_p, _ll, _i, _i, C.POINTER(Ln), _p, _ll, _p]

@@ -239,6 +239,22 @@ class FrozenPlan:
                                     ws.numel(), stop_after, E.stream_ptr()))
         return out
 
+    def profile(self, images, bit_config):
+        """per-launch times (ms, HIP events on the launch stream) of one forward: [(kind_name, ms), ...]."""
+        images = images.contiguous().float()
+        B = images.shape[0]
+        cfg = (C.c_int8 * len(bit_config))(*[int(b) for b in bit_config])
+        ws = self.workspace(B)
+        out = torch.empty(B, self.arch['num_classes'], dtype=torch.float32, device=self.device)
+        n_max = 7 * self.depth + 8
+        ms = (C.c_float * n_max)()
+        kind = (C.c_int32 * n_max)()
+        n = E.lib().p2v_forward_profile(self._handle, E.ptr(images), B, cfg, len(bit_config), E.ptr(out), E.ptr(ws), ws.numel(),
+                                        E.stream_ptr(), ms, kind, n_max)
+        if n < 0:
+            E.check(n)
+        return [(E.KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(n)]
+
     def view(self, batch, name, rows, cols):
         """int8 view of a workspace activation buffer (parity tests)."""
         off = E.lib().p2v_workspace_view(self._handle, batch, name.encode())

@@ -150,6 +150,20 @@ size_t p2v_workspace_bytes(const p2v_plan* plan, int batch);
 int p2v_forward(p2v_plan* plan, const float* images, int batch, const int8_t* bit_config, int n_cfg,
                 float* logits, void* workspace, size_t workspace_bytes, int stop_after, void* stream);
 
+/* Kernel kinds reported by p2v_forward_profile. */
+enum {
+  P2V_K_PATCHIFY = 0, P2V_K_GEMM_EMBED = 1, P2V_K_FILL_CLS = 2, P2V_K_LAYERNORM = 3, P2V_K_GEMM_QKV = 4,
+  P2V_K_ATTENTION = 5, P2V_K_GEMM_PROJ = 6, P2V_K_GEMM_FC1 = 7, P2V_K_GEMM_FC2 = 8, P2V_K_GEMM_HEAD = 9
+};
+
+/* Same as p2v_forward, with a hipEvent recorded on `stream` between consecutive launches; synchronises on the
+ * last event (measurement only -- never call inside a timed region).  Returns the number of launches (>= 0) or
+ * an error; ms_out[i] / kind_out[i] (HOST arrays, max_launches entries) receive the time from launch i to launch
+ * i+1 on the stream and the P2V_K_* kind of launch i. */
+int p2v_forward_profile(p2v_plan* plan, const float* images, int batch, const int8_t* bit_config, int n_cfg,
+                        float* logits, void* workspace, size_t workspace_bytes, void* stream, float* ms_out,
+                        int32_t* kind_out, int max_launches);
+
 /* byte offsets of the named activation buffers inside the workspace for `batch` ("patches", "x", "ln",
  * "qkv", "att", "hid", "cls"); returns <0 for unknown names. */
 long long p2v_workspace_view(const p2v_plan* plan, int batch, const char* name);
