@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the PoT-PTQ quantized DeiT-S forward (int8, 224^2, batch 256 per GPU).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one quantized forward (fp32 images resident in HBM -> int8-grid logits) over one batch of 256
+synthetic images per GPU, followed -- when N>1 -- by the single RCCL all-gather of the logits
+(SURVEY.md 8e).  Weak scaling: per-GPU batch fixed.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODEL, BATCH, SEED = 'deit_small', 256, 3
+PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA: 2x the ~2.5 PF dense bf16 rate (MI355X_MICROARCH.md, Matrix cores: I8 row)
+PEAK_HBM_GBS = 8000.0     # HBM3E spec (same guide)
+
+
+def algorithmic_work(kind, arch, B):
+    """(ops, bytes) of ONE launch of a kernel kind.  ops = 2*MAC of the dense contraction;
+    bytes = compulsory HBM traffic (operands read once + result written once)."""
+    D, H, P = arch['embed_dim'], arch['num_heads'], arch['patch_size']
+    T = (arch['img_size'] // P) ** 2 + 1
+    Hd, M, hd, K0 = int(D * arch['mlp_ratio']), B * T, D // H, 3 * P * P
+    g = lambda m, k, n, out_b=1, extra=0: (2.0 * m * k * n, m * k + n * k + m * n * out_b + extra)
+    return {
+        'patchify': (0.0, B * 3 * arch['img_size'] ** 2 * 4 + B * (T - 1) * K0),
+        'gemm_embed': g(B * (T - 1), K0, D),
+        'fill_cls': (0.0, B * D),
+        'layernorm': (0.0, 2 * M * D),
+        'gemm_qkv': g(M, D, 3 * D),
+        'attention': (4.0 * B * H * T * T * hd, M * 3 * D + M * D),
+        'gemm_proj': g(M, D, D, extra=M * D),
+        'gemm_fc1': g(M, D, Hd),
+        'gemm_fc2': g(M, Hd, D, extra=M * D),
+        'gemm_head': g(B, D, arch['num_classes'], out_b=4),
+    }[kind]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=BATCH, help='images per GPU (BASELINE config 2: 256)')
+    ap.add_argument('--bits', type=int, default=8, choices=(4, 8))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    import diff_vit_amd as dva
+    from diff_vit_amd import calib_io
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    arch = dva.synth.ARCHS[MODEL]
+    sd = dva.synth.vit_state_dict(arch, SEED)
+    # calibration state produced by the REAL reference on these weights (oracle/gen_golden.py)
+    calib = calib_io.load_npz(os.path.join(ROOT, 'tests', 'golden', 'deit_small.npz'))
+    plan = dva.FrozenPlan(arch, sd, calib, device=dev)
+    B = args.batch
+    # 32 distinct synthetic images per rank, tiled to the batch (content does not change the work)
+    base = dva.synth.images(1000 + rank, min(B, 32), arch['img_size'])
+    x = base.repeat((B + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
+    bits = [args.bits] * (4 * arch['depth'] + 2)
+    logits = torch.empty(B, arch['num_classes'], device=dev)
+    gathered = torch.empty(world * B, arch['num_classes'], device=dev) if world > 1 else None
+
+    def step():
+        plan.forward(x, bits, out=logits)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, logits)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    value = world * B * args.steps / el
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, measured live ----------------------
+    prof = {}
+    for _ in range(5):
+        for kind, ms in plan.profile(x, bits):
+            prof.setdefault(kind, []).append(ms)
+    tot = {k: sum(v) / 5 for k, v in prof.items()}
+    dom = max(tot, key=tot.get)
+    avg_ms = sum(prof[dom]) / len(prof[dom])
+    ops, byts = algorithmic_work(dom, arch, B)
+    if ops > 0:
+        ach = ops / (avg_ms * 1e-3) / 1e12
+        roof = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=PEAK_INT8_TOPS, unit='TFLOP/s',
+                    frac=round(ach / PEAK_INT8_TOPS, 4))
+    else:
+        ach = byts / (avg_ms * 1e-3) / 1e9
+        roof = dict(kernel=dom, bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                    frac=round(ach / PEAK_HBM_GBS, 4))
+    roof['avg_launch_us'] = round(avg_ms * 1e3, 2)
+    roof['launches_per_step'] = len(prof[dom]) // 5
+    roof['traffic'] = None
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
+    if os.path.exists(pmc):
+        try:
+            roof['traffic'] = json.load(open(pmc)).get(dom)
+        except Exception:
+            pass
+    breakdown = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
+    model_ops = sum(algorithmic_work(k, arch, B)[0] * (len(v) // 5) for k, v in prof.items())
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import p2vit_oracle as O           # test infrastructure: used here ONLY as the timed CPU baseline
+        orc = O.OracleViT(arch, sd)
+        orc.calib = calib
+        nb = 16
+        xc = x[:nb].cpu()
+        with torch.no_grad():
+            orc.quant_forward(xc, bits)
+            t1 = time.perf_counter()
+            iters = 0
+            while iters < 2 or (time.perf_counter() - t1 < 10 and iters < 20):
+                ref = orc.quant_forward(xc, bits)
+                iters += 1
+            tc = time.perf_counter() - t1
+        same = bool(torch.equal(ref, logits[:nb].cpu()))
+        cpu = dict(value=round(nb * iters / tc, 2), unit='images/sec', cores=torch.get_num_threads(), kind='port',
+                   sample='%d forwards of %d images (same weights/bits), oracle/p2vit_oracle.py torch-CPU restatement' % (iters, nb),
+                   logits_equal_gpu=same)
+
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'images/sec DeiT-S int8 224^2 b=256 (quantized forward)', 'value': round(value, 1), 'unit': 'images/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(el / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int%d' % args.bits if args.bits == 8 else 'int4w/int8a',
+            'data': 'synthetic',
+            'config': {'workload': 'deit_small PoT-PTQ forward, bit_config=[%d]*50, 224x224, batch %d per GPU' % (args.bits, B),
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world,
+                       'collective': 'all_gather(logits)' if world > 1 else 'none'},
+            'roofline': roof,
+            'model_mfma_frac': round(model_ops / (el / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
+            'kernel_ms_per_step': breakdown,
+            'cpu_baseline': cpu,
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

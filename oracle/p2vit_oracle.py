@@ -22,7 +22,8 @@ machine-independent reading, which the HIP kernels reproduce bit for bit:
   - every contraction / reduction over integer-valued data is EXACT (int64 / exact fp32), followed by
     the single fp32 rounding the reference applies next;
   - every elementwise fp32 operation is performed in the reference's order with IEEE fp32 ops;
-  - ``floor(log2(x))`` is the exact binary exponent (frexp);  ``2**n`` is exact (ldexp);
+  - ``floor(log2(x))`` is the exact binary exponent (frexp);  ``2**n`` is exact (ldexp);  ``sqrt`` is the
+    correctly rounded IEEE value (torch.sqrt on CPU is MKL-VML and differs between Xeon and EPYC hosts);
   - GELU is the correctly-rounded fp32 value of 0.5*y*erfc(-y/sqrt(2)) (evaluated in fp64).
 
 Pinning: ``oracle/gen_golden.py`` imports the real reference in the build container and stores its
@@ -245,7 +246,9 @@ def int_layernorm(x, in_scale, gamma, beta, out_scale):
     S1 = xd.sum(dim=-1).float()
     S2 = (xd * xd).sum(dim=-1).float()
     mean = (S1 / C) * s1
-    std = (s1 / C) * torch.sqrt(C * S2 - S1 * S1)
+    # torch.sqrt on CPU goes through MKL VML and is NOT correctly rounded (0x4e3d094f -> ...1b on Xeon, ...1c on
+    # EPYC): take the IEEE value (fp64 sqrt rounded once), which is what v_sqrt_f32 / CUDA sqrtf return
+    std = (s1 / C) * torch.sqrt((C * S2 - S1 * S1).double()).float()
     A = (s1 / std).unsqueeze(-1) * g / out_scale
     sign = A.sign()
     absA = A.abs()
