@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -49,7 +50,15 @@ static int bit_index(int bits) { return bits == 4 ? 0 : (bits == 8 ? 1 : -1); }
 
 extern "C" {
 
-int p2v_abi_version(void) { return P2V_ABI_VERSION; }
+extern int g_use_panel;
+static void read_env_once() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  const char* e = getenv("P2V_GEMM_PANEL");
+  if (e) g_use_panel = (e[0] == '1');
+}
+int p2v_abi_version(void) { read_env_once(); return P2V_ABI_VERSION; }
 const char* p2v_last_error(void) { return g_err; }
 
 int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {

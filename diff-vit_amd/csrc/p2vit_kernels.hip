@@ -57,29 +57,91 @@ __device__ __forceinline__ void row16_to_halves(uint4 e, unsigned& g0, unsigned&
 // elements) the lane takes the fp64 path.  tests/test_gelu_gpu.py sweeps the fp32 line to check the bound.
 // ---------------------------------------------------------------------------------------------------
 #define GELU_EPS 4.0e-6f
+// approximation only (its error is bounded by the exhaustive sweep in tests): fused multiply-adds are fine here
 __device__ __forceinline__ float gelu_fast(float y) {
-  float z = fabsf(y) * 0.70710678f;
-  float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  float e = __builtin_amdgcn_exp2f(-(z * z) * 1.44269504f);
-  float hc = 0.5f * p * e;  // 0.5*erfc(|y|/sqrt2)
-  return y < 0.f ? y * hc : y - y * hc;
+  const float z = fabsf(y) * 0.70710678f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = __builtin_fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);       // 0.5 * A&S 7.1.26 polynomial
+  p = __builtin_fmaf(t, p, 0.5f * 1.421413741f);
+  p = __builtin_fmaf(t, p, 0.5f * -0.284496736f);
+  p = __builtin_fmaf(t, p, 0.5f * 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504f);
+  const float hc = (p * t) * e;                     // 0.5*erfc(|y|/sqrt2) = Phi(-|y|)
+  return fmaxf(y, 0.f) - fabsf(y) * hc;             // y*Phi(y) = relu(y) - |y|*Phi(-|y|)
 }
 __device__ __noinline__ float gelu_exact(float y) {
   double yd = (double)y;
   return (float)(0.5 * yd * erfc(-yd * 0.70710678118654752440));
 }
+// clamp(rne(x), -128, 127) of an fp32 value that is within `eps` (absolute) of the exact pre-rounding value:
+// decided iff x is further than eps from a rounding boundary.  (|x| >= 2^23 has no fraction: always decided.)
+__device__ __forceinline__ bool rne_decided(float x, float r, float eps) { return fabsf(x - r) < 0.5f - eps; }
+
 __device__ __forceinline__ int gelu_q8(float y, float inv_s, bool force_slow, bool* took_slow) {
-  float g = gelu_fast(y);
-  float t = g * inv_s;
+  const float t = gelu_fast(y) * inv_s;
   float r = rintf(t);
-  bool safe = (fabsf(t - r) < 0.5f - GELU_EPS * inv_s) || (fabsf(t) > 129.f);
-  if (force_slow || !safe || !(GELU_EPS * inv_s < 0.25f)) {
-    if (took_slow) *took_slow = true;
-    r = rintf(gelu_exact(y) * inv_s);
+  const bool slow = force_slow || !rne_decided(t, r, GELU_EPS * inv_s) || !(GELU_EPS * inv_s < 0.25f);
+  if (__builtin_amdgcn_ballot_w64(slow) != 0) {           // wave-uniform branch: ~1e-4 of the lanes need the fp64 value
+    if (slow) {
+      if (took_slow) *took_slow = true;
+      r = rintf(gelu_exact(y) * inv_s);
+    }
   }
   r = fminf(fmaxf(r, -128.f), 127.f);
   return (int)r;
+}
+
+// Four at a time: the fast values are computed branch-free (instruction-level parallelism across the four
+// dependent chains), ONE wave-uniform branch covers the rare lanes that need the fp64 value.
+__device__ __forceinline__ void gelu_q8x4(const float (&y)[4], float inv_s, int (&q)[4]) {
+  float r[4];
+  bool slow[4], any = !(GELU_EPS * inv_s < 0.25f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float t = gelu_fast(y[i]) * inv_s;
+    r[i] = rintf(t);
+    slow[i] = !rne_decided(t, r[i], GELU_EPS * inv_s);
+    any |= slow[i];
+  }
+  if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (slow[i] || !(GELU_EPS * inv_s < 0.25f)) r[i] = rintf(gelu_exact(y[i]) * inv_s);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = (int)fminf(fmaxf(r[i], -128.f), 127.f);
+}
+
+// clamp(rne(x / s), -128, 127) with IEEE-division semantics (the reference divides by the non-power-of-two
+// PTF scales, ptf.py:133) at the price of one multiply: t = x * fl(1/s) is within 2^-23 |t| of the true
+// quotient and fl(x/s) within 2^-24 |t|; below |t| = 256 that is < 5e-5, so when t is further than 1e-4 from a
+// rounding boundary both round to the same integer; above 256 both clamp.  Otherwise (2e-4 of the lanes) divide.
+__device__ __forceinline__ float div_q8f(float x, float s, float rs) {
+  const float t = x * rs;
+  float r = rintf(t);
+  const bool slow = !rne_decided(t, r, 1.0e-4f);
+  if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+    if (slow) r = rintf(x / s);
+  }
+  return fminf(fmaxf(r, -128.f), 127.f);
+}
+__device__ __forceinline__ void div_q8fx4(const float (&x)[4], const float (&s)[4], const float (&rs)[4], float (&out)[4]) {
+  float r[4];
+  bool slow[4], any = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float t = x[i] * rs[i];
+    r[i] = rintf(t);
+    slow[i] = !rne_decided(t, r[i], 1.0e-4f);
+    any |= slow[i];
+  }
+  if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (slow[i]) r[i] = rintf(x[i] / s[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = fminf(fmaxf(r[i], -128.f), 127.f);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -127,18 +189,41 @@ __global__ void k_fill_cls(int8_t* __restrict__ x, int B, int T, int D, const in
 
 __device__ __forceinline__ int lds_off64(int row, int chunk) { return row * GBK + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
+// per-block staging of the per-channel epilogue constants (read by every lane of the block)
+struct EpiLds {
+  float colscale[GBN], bias[GBN], s_mid[GBN], s_res[GBN], s_next[GBN], r_mid[GBN], r_next[GBN];
+};
+
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n_tile, int h, const GemmArgs& g) {
-  // lane owns output row m, channels n_tile + 8*gq + 4*h + {0..3}, gq = 0..3   (C/D map of 32x32 MFMA)
+__device__ __forceinline__ void gemm_stage_epilogue(EpiLds* e, int n0, int tid, const GemmArgs& g) {
+  if (tid < GBN) {
+    const int n = n0 + tid;
+    e->colscale[tid] = g.colscale[n];                 // arrays are padded to n_pad
+    e->bias[tid] = g.bias[n];
+    const bool ok = n < g.N;
+    if (EPI == P2V_EPI_RESID) {
+      const float sm = ok ? g.ep.s_mid[n] : 1.f;
+      e->s_mid[tid] = sm;
+      e->r_mid[tid] = 1.0f / sm;
+      e->s_res[tid] = ok ? g.ep.s_res[n] : 1.f;
+    }
+    if (EPI == P2V_EPI_RESID || EPI == P2V_EPI_EMBED) {
+      const float sn = ok ? g.ep.s_next[n] : 1.f;
+      e->s_next[tid] = sn;
+      e->r_next[tid] = 1.0f / sn;
+    }
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n_tile, int nl, int h, const GemmArgs& g,
+                                                   const EpiLds* e, uint4 resv) {
+  // lane owns output row m, channels n_tile + 8*gq + 4*h + {0..3}, gq = 0..3   (C/D map of 32x32 MFMA);
+  // nl = n_tile - n0 (column offset inside the block tile, for the LDS constants)
   const bool row_ok = m < g.M;
   unsigned d[4];
   unsigned res[4];
-  if (EPI == P2V_EPI_RESID) {
-    uint4 e = make_uint4(0, 0, 0, 0);
-    if (row_ok && n_tile + 16 * h < g.N)
-      e = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n_tile + 16 * h);
-    row16_to_halves(e, res[0], res[1], res[2], res[3]);
-  }
+  if (EPI == P2V_EPI_RESID) row16_to_halves(resv, res[0], res[1], res[2], res[3]);
   long long out_row = m;
   int tok = 0;
   if (EPI == P2V_EPI_EMBED) {
@@ -148,52 +233,55 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
   }
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
-    const int n = n_tile + 8 * gq + 4 * h;
-    const float4 cs = *reinterpret_cast<const float4*>(g.colscale + n);
-    const float4 bs = *reinterpret_cast<const float4*>(g.bias + n);
+    const int n = n_tile + 8 * gq + 4 * h, c = nl + 8 * gq + 4 * h;
+    const float4 cs = *reinterpret_cast<const float4*>(e->colscale + c);
+    const float4 bs = *reinterpret_cast<const float4*>(e->bias + c);
     float y[4];
     // F.linear / F.conv2d on fake-quantised operands: exact integer sum * (s_x*s_w[n]), then ONE rounding
-    // for the fp32 bias (layers.py:87,178)
-    y[0] = (float)acc[4 * gq + 0] * cs.x + bs.x;
-    y[1] = (float)acc[4 * gq + 1] * cs.y + bs.y;
-    y[2] = (float)acc[4 * gq + 2] * cs.z + bs.z;
-    y[3] = (float)acc[4 * gq + 3] * cs.w + bs.w;
+    // for the fp32 bias (layers.py:87,178).  The product int * 2^k is exact, so the fused multiply-add rounds
+    // exactly once, like mul-then-add does.
+    y[0] = __builtin_fmaf((float)acc[4 * gq + 0], cs.x, bs.x);
+    y[1] = __builtin_fmaf((float)acc[4 * gq + 1], cs.y, bs.y);
+    y[2] = __builtin_fmaf((float)acc[4 * gq + 2], cs.z, bs.z);
+    y[3] = __builtin_fmaf((float)acc[4 * gq + 3], cs.w, bs.w);
     int q[4];
     if (EPI == P2V_EPI_REQUANT) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) q[i] = sat8(y[i] * g.ep.inv_s_out);
     } else if (EPI == P2V_EPI_GELU) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) q[i] = gelu_q8(y[i], g.ep.inv_s_out, false, nullptr);
+      gelu_q8x4(y, g.ep.inv_s_out, q);
     } else if (EPI == P2V_EPI_RESID) {
       // QAct(PTF) -> x + . -> QAct(PTF): non power-of-two per-channel scales, true fp32 divisions
-      float4 sm = make_float4(1, 1, 1, 1), sr = sm, sn = sm;
-      if (n < g.N) {
-        sm = *reinterpret_cast<const float4*>(g.ep.s_mid + n);
-        sr = *reinterpret_cast<const float4*>(g.ep.s_res + n);
-        sn = *reinterpret_cast<const float4*>(g.ep.s_next + n);
-      }
+      const float4 sm = *reinterpret_cast<const float4*>(e->s_mid + c);
+      const float4 sr = *reinterpret_cast<const float4*>(e->s_res + c);
+      const float4 sn = *reinterpret_cast<const float4*>(e->s_next + c);
+      const float4 rm = *reinterpret_cast<const float4*>(e->r_mid + c);
+      const float4 rn = *reinterpret_cast<const float4*>(e->r_next + c);
       const float smv[4] = {sm.x, sm.y, sm.z, sm.w}, srv[4] = {sr.x, sr.y, sr.z, sr.w}, snv[4] = {sn.x, sn.y, sn.z, sn.w};
+      const float rmv[4] = {rm.x, rm.y, rm.z, rm.w}, rnv[4] = {rn.x, rn.y, rn.z, rn.w};
+      float q3[4], xs[4], qo[4];
+      div_q8fx4(y, smv, rmv, q3);                                      // qact3 / mlp.qact2 (PTF) codes
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float x3 = (float)sat8(y[i] / smv[i]) * smv[i];
-        float xr = (float)sx8(res[gq], i) * srv[i];
-        q[i] = sat8((xr + x3) / snv[i]);
-      }
+      for (int i = 0; i < 4; ++i) xs[i] = (float)sx8(res[gq], i) * srv[i] + q3[i] * smv[i];   // x + dequantised branch
+      div_q8fx4(xs, snv, rnv, qo);                                     // Block.qact2 / qact4 (PTF)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = (int)qo[i];
     } else if (EPI == P2V_EPI_EMBED) {
-      float4 sn = make_float4(1, 1, 1, 1), pe = make_float4(0, 0, 0, 0);
-      if (n < g.N) {
-        sn = *reinterpret_cast<const float4*>(g.ep.s_next + n);
-        pe = *reinterpret_cast<const float4*>(g.ep.pos_deq + (long long)tok * g.N + n);
-      }
-      const float snv[4] = {sn.x, sn.y, sn.z, sn.w}, pev[4] = {pe.x, pe.y, pe.z, pe.w};
+      const float4 sn = *reinterpret_cast<const float4*>(e->s_next + c);
+      const float4 rn = *reinterpret_cast<const float4*>(e->r_next + c);
+      float4 pe = make_float4(0, 0, 0, 0);
+      if (n < g.N) pe = *reinterpret_cast<const float4*>(g.ep.pos_deq + (long long)tok * g.N + n);
+      const float snv[4] = {sn.x, sn.y, sn.z, sn.w}, pev[4] = {pe.x, pe.y, pe.z, pe.w}, rnv[4] = {rn.x, rn.y, rn.z, rn.w};
+      float xv[4], qo[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int q1 = sat8(y[i] * g.ep.inv_s_pe);                  // PatchEmbed.qact
         int q2 = sat8((float)q1 * g.ep.pe_to_embed);          // qact_embed (both PoT: exact ratio)
-        float xv = (float)q2 * g.ep.s_embed + pev[i];         // + qact_pos(pos_embed)
-        q[i] = sat8(xv / snv[i]);                             // qact1 (PTF)
+        xv[i] = __builtin_fmaf((float)q2, g.ep.s_embed, pev[i]);   // + qact_pos(pos_embed); int*2^k exact -> one rounding
       }
+      div_q8fx4(xv, snv, rnv, qo);                            // qact1 (PTF)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = (int)qo[i];
     } else {  // HEAD: logits fp32 on the act_out grid
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -213,11 +301,33 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
   }
 }
 
+// one k-tile of MFMA work for a wave: 2 k-steps x (2 weight frags, 2 activation frags, 4 MFMAs)
+__device__ __forceinline__ void gemm_compute_tile(const int8_t* cx, const int8_t* cw, int wm, int wn, int l31, int h, v16i (&acc)[2][2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    v4i fw[2], fx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fw[i] = *reinterpret_cast<const v4i*>(cw + lds_off64(wn * 64 + i * 32 + l31, 2 * ks + h));
+      fx[i] = *reinterpret_cast<const v4i*>(cx + lds_off64(wm * 64 + i * 32 + l31, 2 * ks + h));
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        acc[ni][mi] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[ni], fx[mi], acc[ni][mi], 0, 0, 0);
+  }
+}
+
+// Generic tiled GEMM.  Global->LDS staging goes through a 3-deep ring of NAMED registers (an indexed array
+// of prefetch registers is placed in scratch by hipcc: measured, 80 B private segment and a scratch round trip
+// per k-tile): tile t+3 is requested while tile t is computed, one barrier per k-tile.
 template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_i8(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) int8_t lds[2 * (GBM + GBN) * GBK];
+__global__ __launch_bounds__(256, EPI == P2V_EPI_RESID ? 2 : 3) void k_gemm_i8(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) int8_t lds[2 * (GBM + GBN) * GBK + sizeof(EpiLds)];
   int8_t* sX = lds;                    // [2][GBM][GBK] activation rows
   int8_t* sW = lds + 2 * GBM * GBK;    // [2][GBN][GBK] weight rows
+  EpiLds* sE = reinterpret_cast<EpiLds*>(lds + 2 * (GBM + GBN) * GBK);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -229,16 +339,15 @@ __global__ __launch_bounds__(256) void k_gemm_i8(GemmArgs g) {
   const int m0 = tm * GBM, n0 = tn * GBN;
 
   const int lrow = tid >> 2, lchunk = tid & 3;
-  const int8_t* gx[2];
-  const int8_t* gwp[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int r = lrow + 64 * i;
-    int mr = m0 + r;
-    mr = mr < g.M ? mr : g.M - 1;
-    gx[i] = g.A + (long long)mr * g.lda + lchunk * 16;
-    gwp[i] = g.W + (long long)(n0 + r) * g.K + lchunk * 16;
-  }
+  int mr0 = m0 + lrow, mr1 = m0 + lrow + 64;
+  mr0 = mr0 < g.M ? mr0 : g.M - 1;
+  mr1 = mr1 < g.M ? mr1 : g.M - 1;
+  const int8_t* gx0 = g.A + (long long)mr0 * g.lda + lchunk * 16;
+  const int8_t* gx1 = g.A + (long long)mr1 * g.lda + lchunk * 16;
+  const int8_t* gw0 = g.W + (long long)(n0 + lrow) * g.K + lchunk * 16;
+  const int8_t* gw1 = g.W + (long long)(n0 + lrow + 64) * g.K + lchunk * 16;
+  const int o0 = lds_off64(lrow, lchunk), o1 = lds_off64(lrow + 64, lchunk);
+
   v16i acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -248,61 +357,176 @@ __global__ __launch_bounds__(256) void k_gemm_i8(GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
 
   const int nk = g.K / GBK;
-  uint4 rx[2], rw[2];
+  uint4 ax0, ax1, aw0, aw1, bx0, bx1, bw0, bw1, cx0, cx1, cw0, cw1;
+#define G_LOAD(P, T)                                                        \
+  do {                                                                      \
+    P##x0 = *reinterpret_cast<const uint4*>(gx0 + (T) * GBK);               \
+    P##x1 = *reinterpret_cast<const uint4*>(gx1 + (T) * GBK);               \
+    P##w0 = *reinterpret_cast<const uint4*>(gw0 + (T) * GBK);               \
+    P##w1 = *reinterpret_cast<const uint4*>(gw1 + (T) * GBK);               \
+  } while (0)
+#define G_STEP(P, T)                                                        \
+  do {                                                                      \
+    int8_t* bx_ = sX + ((T) & 1) * GBM * GBK;                               \
+    int8_t* bw_ = sW + ((T) & 1) * GBN * GBK;                               \
+    *reinterpret_cast<uint4*>(bx_ + o0) = P##x0;                            \
+    *reinterpret_cast<uint4*>(bx_ + o1) = P##x1;                            \
+    *reinterpret_cast<uint4*>(bw_ + o0) = P##w0;                            \
+    *reinterpret_cast<uint4*>(bw_ + o1) = P##w1;                            \
+    __syncthreads();                                                        \
+    if ((T) + 3 < nk) G_LOAD(P, (T) + 3);                                   \
+    gemm_compute_tile(bx_, bw_, wm, wn, l31, h, acc);                       \
+  } while (0)
+  G_LOAD(a, 0);
+  if (nk > 1) G_LOAD(b, 1);
+  if (nk > 2) G_LOAD(c, 2);
+  gemm_stage_epilogue<EPI>(sE, n0, tid, g);        // visible after the first barrier of the k loop
+  uint4 resv[2][2];                                // residual codes of this lane's 4 output tiles, requested early
+  if (EPI == P2V_EPI_RESID) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    rx[i] = *reinterpret_cast<const uint4*>(gx[i]);
-    rw[i] = *reinterpret_cast<const uint4*>(gwp[i]);
-  }
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int r = lrow + 64 * i;
-    *reinterpret_cast<uint4*>(sX + lds_off64(r, lchunk)) = rx[i];
-    *reinterpret_cast<uint4*>(sW + lds_off64(r, lchunk)) = rw[i];
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        rx[i] = *reinterpret_cast<const uint4*>(gx[i] + (kt + 1) * GBK);
-        rw[i] = *reinterpret_cast<const uint4*>(gwp[i] + (kt + 1) * GBK);
+      for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 64 + ni * 32 + 16 * h;
+        resv[ni][mi] = make_uint4(0, 0, 0, 0);
+        if (m < g.M && n < g.N) resv[ni][mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
       }
-    }
-    const int8_t* cx = sX + cur * GBM * GBK;
-    const int8_t* cw = sW + cur * GBN * GBK;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      v4i fw[2], fx[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fw[i] = *reinterpret_cast<const v4i*>(cw + lds_off64(wn * 64 + i * 32 + l31, 2 * ks + h));
-        fx[i] = *reinterpret_cast<const v4i*>(cx + lds_off64(wm * 64 + i * 32 + l31, 2 * ks + h));
-      }
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[ni], fx[mi], acc[ni][mi], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-      int8_t* nx = sX + (cur ^ 1) * GBM * GBK;
-      int8_t* nw = sW + (cur ^ 1) * GBN * GBK;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        int r = lrow + 64 * i;
-        *reinterpret_cast<uint4*>(nx + lds_off64(r, lchunk)) = rx[i];
-        *reinterpret_cast<uint4*>(nw + lds_off64(r, lchunk)) = rw[i];
-      }
-    }
-    __syncthreads();
   }
+  for (int kt = 0; kt < nk; kt += 3) {
+    G_STEP(a, kt);
+    if (kt + 1 < nk) G_STEP(b, kt + 1);
+    if (kt + 2 < nk) G_STEP(c, kt + 2);
+  }
+#undef G_LOAD
+#undef G_STEP
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
-      gemm_epilogue_tile<EPI>(acc[ni][mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 64 + ni * 32, h, g);
+      gemm_epilogue_tile<EPI>(acc[ni][mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, sE,
+                              EPI == P2V_EPI_RESID ? resv[ni][mi] : make_uint4(0, 0, 0, 0));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1b: "panel" GEMM for K <= 384 (qkv, fc1, proj of DeiT-T/S and the micro model).
+//   The activation panel [128 rows][K] is read from HBM once per work item and stays in LDS while the block
+//   walks `tpg` consecutive 128-column weight tiles (from L2).  The next weight tile and its epilogue
+//   constants are requested BEFORE the MFMAs of the current tile and land during its epilogue, which is the
+//   long phase (fp32 requant / GELU: VALU bound), so the block never waits on memory after its prologue.
+//   8 waves (2 per SIMD, so one wave's epilogue VALU overlaps its partner's MFMAs): wave = 64 rows x 32 cols.
+//   LDS: panel KP*128 + 2 weight tiles KP*128 each + 2 constant sets  (149 KB at K = 384) -> one block per CU.
+// ---------------------------------------------------------------------------------------------------
+template <int EPI, int KP>
+__global__ __launch_bounds__(512, 2) void k_gemm_panel(GemmArgs g, int tpg) {
+  constexpr int NKT = KP / GBK;                  // 64-byte k-tiles
+  constexpr int TILE = GBM * GBK;                // bytes of one [128][64] swizzled sub-tile
+  constexpr int NLD = (GBM * KP / 16) / 512;     // uint4 loads per thread for a [128][KP] operand
+  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+  int8_t* sA = reinterpret_cast<int8_t*>(psm);                         // [NKT][128][64]
+  int8_t* sW = sA + NKT * TILE;                                         // [2][NKT][128][64]
+  EpiLds* sE = reinterpret_cast<EpiLds*>(sW + 2 * NKT * TILE);          // [2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int groups = (g.tiles_n + tpg - 1) / tpg;
+  int bid = blockIdx.x, nt = gridDim.x, xcd = bid & 7, qd = nt >> 3, rm = nt & 7;
+  const int item = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  const int mp = item / groups, ng = item % groups;
+  const int m0 = mp * GBM;
+  const int t0 = ng * tpg;
+  const int ntile = (t0 + tpg <= g.tiles_n) ? tpg : g.tiles_n - t0;
+
+  // operand element (row, 16-byte chunk) handled by this thread for load slot i: e = tid + 512*i.
+  // The staging registers are NAMED (w0..w5 / a0..a5): hipcc places an indexed, loop-carried uint4 array in
+  // scratch (measured: 112 B private segment, scratch_store/load per tile).
+#define P2V_FOREACH6(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5)
+#define P2V_ROWCH(i) const int e_ = tid + 512 * (i), row_ = e_ / (KP / 16), ch_ = e_ % (KP / 16)
+  uint4 w0, w1, w2, w3, w4, w5;
+  {
+    uint4 a0, a1, a2, a3, a4, a5;
+#define P2V_LD(i)                                                                                          \
+    if ((i) < NLD) {                                                                                       \
+      P2V_ROWCH(i);                                                                                        \
+      int mr_ = m0 + row_;                                                                                 \
+      mr_ = mr_ < g.M ? mr_ : g.M - 1;                                                                     \
+      a##i = *reinterpret_cast<const uint4*>(g.A + (long long)mr_ * g.lda + ch_ * 16);                     \
+      w##i = *reinterpret_cast<const uint4*>(g.W + (long long)(t0 * GBN + row_) * g.K + ch_ * 16);         \
+    }
+    P2V_FOREACH6(P2V_LD)
+#undef P2V_LD
+#define P2V_ST(i)                                                                                          \
+    if ((i) < NLD) {                                                                                       \
+      P2V_ROWCH(i);                                                                                        \
+      const int off_ = (ch_ >> 2) * TILE + lds_off64(row_, ch_ & 3);                                       \
+      *reinterpret_cast<uint4*>(sA + off_) = a##i;                                                         \
+      *reinterpret_cast<uint4*>(sW + off_) = w##i;                                                         \
+    }
+    P2V_FOREACH6(P2V_ST)
+#undef P2V_ST
+  }
+  gemm_stage_epilogue<EPI>(&sE[0], t0 * GBN, tid, g);
+  __syncthreads();
+
+  for (int j = 0; j < ntile; ++j) {
+    const int n0 = (t0 + j) * GBN;
+    const bool more = j + 1 < ntile;
+    {
+      // unconditional (the last step re-reads its own tile from L2): a conditional refill of a loop-carried
+      // register array is placed in scratch by hipcc
+      const int nn = more ? n0 + GBN : n0;
+#define P2V_LW(i)                                                                                          \
+      if ((i) < NLD) {                                                                                     \
+        P2V_ROWCH(i);                                                                                      \
+        w##i = *reinterpret_cast<const uint4*>(g.W + (long long)(nn + row_) * g.K + ch_ * 16);             \
+      }
+      P2V_FOREACH6(P2V_LW)
+#undef P2V_LW
+    }
+    uint4 resv[2];
+    if (EPI == P2V_EPI_RESID) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 32 + 16 * h;
+        resv[mi] = make_uint4(0, 0, 0, 0);
+        if (m < g.M && n < g.N) resv[mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
+      }
+    }
+    v16i acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] = 0;
+    const int8_t* cw = sW + (j & 1) * NKT * TILE;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const v4i fw = *reinterpret_cast<const v4i*>(cw + kt * TILE + lds_off64(wn * 32 + l31, 2 * ks + h));
+        const v4i f0 = *reinterpret_cast<const v4i*>(sA + kt * TILE + lds_off64(wm * 64 + l31, 2 * ks + h));
+        const v4i f1 = *reinterpret_cast<const v4i*>(sA + kt * TILE + lds_off64(wm * 64 + 32 + l31, 2 * ks + h));
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw, f0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw, f1, acc[1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+      gemm_epilogue_tile<EPI>(acc[mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 32, wn * 32, h, g, &sE[j & 1],
+                              EPI == P2V_EPI_RESID ? resv[mi] : make_uint4(0, 0, 0, 0));
+    if (more) {
+      int8_t* nw = sW + ((j + 1) & 1) * NKT * TILE;     // last read two steps ago, behind the previous barrier
+#define P2V_SW(i)                                                                                          \
+      if ((i) < NLD) {                                                                                     \
+        P2V_ROWCH(i);                                                                                      \
+        *reinterpret_cast<uint4*>(nw + (ch_ >> 2) * TILE + lds_off64(row_, ch_ & 3)) = w##i;               \
+      }
+      P2V_FOREACH6(P2V_SW)
+#undef P2V_SW
+      gemm_stage_epilogue<EPI>(&sE[(j + 1) & 1], n0 + GBN, tid, g);
+    }
+    __syncthreads();
+  }
+#undef P2V_FOREACH6
+#undef P2V_ROWCH
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -311,7 +535,7 @@ __global__ __launch_bounds__(256) void k_gemm_i8(GemmArgs g) {
 // wave so the five per-channel constant vectors stay in registers.  sum x and sum x^2 are exact integers;
 // everything after mirrors the reference's fp32 operation order.
 // ---------------------------------------------------------------------------------------------------
-#define LN_ROWS 8
+#define LN_ROWS 2
 template <int NCH>
 __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
   const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
@@ -331,23 +555,34 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
   const float s1 = a.ln.s1;
   const float Cf = (float)a.C;
   const long long row0 = ((long long)blockIdx.x * 8 + hw) * LN_ROWS;
+  unsigned wnext[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+    wnext[i] = (on[i] && row0 < a.rows) ? *reinterpret_cast<const unsigned*>(a.x + row0 * a.row_stride + (l32 + 32 * i) * 4) : 0u;
   for (int rr = 0; rr < LN_ROWS; ++rr) {
     const long long row = row0 + rr;
     if (row >= a.rows) break;   // uniform within the half wave; shuffles below use width 32
-    const int8_t* src = a.x + row * a.row_stride;
+    unsigned wcur[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) wcur[i] = wnext[i];
+    if (rr + 1 < LN_ROWS && row + 1 < a.rows) {   // request the next row before the arithmetic of this one
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+        if (on[i]) wnext[i] = *reinterpret_cast<const unsigned*>(a.x + (row + 1) * a.row_stride + (l32 + 32 * i) * 4);
+    }
     float xq[NCH][4];
     int S1 = 0;
-    long long S2 = 0;
+    int S2 = 0;                                   // C * (128*8)^2 < 2^31 for C < 2048: exact in 32 bits
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      unsigned w = on[i] ? *reinterpret_cast<const unsigned*>(src + (l32 + 32 * i) * 4) : 0u;
+      const unsigned w = wcur[i];
       const float m4[4] = {mk[i].x, mk[i].y, mk[i].z, mk[i].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int v = on[i] ? sx8(w, j) * (int)m4[j] : 0;   // x_q * in_scale_mask  (layers.py:269-273)
+        int v = on[i] ? __mul24(sx8(w, j), (int)m4[j]) : 0;   // x_q * in_scale_mask  (layers.py:269-273)
         xq[i][j] = (float)v;
         S1 += v;
-        S2 += (long long)(v * v);
+        S2 += __mul24(v, v);
       }
     }
 #pragma unroll
@@ -370,16 +605,12 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
       for (int j = 0; j < 4; ++j) {
         const float A = (rs * g4[j]) * i4[j];                            // (s1/std)*gamma / out_scale
         const float absA = fabsf(A);
-        const int eA = (int)((__float_as_uint(absA) >> 23) & 255u) - 127; // floor(log2|A|)
-        int N = 7 - eA;                                                  // get_MN, layers.py:234-238
+        int N = 134 - (int)(__float_as_uint(absA) >> 23);                // 7 - floor(log2|A|)   (get_MN, layers.py:234-238)
         N = N < 0 ? 0 : (N > 31 ? 31 : N);
-        const float pN = __uint_as_float((unsigned)(127 + N) << 23);
-        const float inN = __uint_as_float((unsigned)(127 - N) << 23);
-        float M = floorf(absA * pN);
-        M = fminf(M, 255.f);
-        const float sM = A < 0.f ? -M : (A > 0.f ? M : 0.f);             // A.sign() * M
-        const float Bv = rintf(((b4[j] - mos * g4[j]) * i4[j]) * pN);    // layers.py:283-286
-        const float o = rintf((sM * xq[i][j] + Bv) * inN);               // layers.py:288
+        const float M = fminf(floorf(ldexpf(absA, N)), 255.f);           // floor(|A| * 2^N), clamped
+        const float sM = copysignf(M, A);                                // A.sign() * M  (M == 0 when A == 0)
+        const float Bv = rintf(ldexpf((b4[j] - mos * g4[j]) * i4[j], N));   // layers.py:283-286
+        const float o = rintf(ldexpf(sM * xq[i][j] + Bv, -N));           // layers.py:288
         q[j] = sat8(o * p4[j]);                                          // * out_scale / cs_next / s_next
       }
       outw[i] = pack4(q[0], q[1], q[2], q[3]);
@@ -393,32 +624,38 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // K3: fused attention core  (vit_fquant.py:309-326; QIntSoftmax layers.py:323-376)
-//   one workgroup per (image, head); K (int8) and V^T (bf16) staged in LDS; each wave owns 32-query
-//   blocks.  S^T = K . Q^T on the int8 MFMA puts a whole score row on one lane pair, so the row max and
-//   the exact int64 sum of exp_int = z * 2^(32-q) are in-lane plus one cross-half shuffle.  exp_int
-//   depends only on (max - score) in [0,255]: a 256-entry LDS table.  P = 2^-k is exact in bf16 and V
-//   codes are exact in bf16, so P.V on the bf16 MFMA is exact in its fp32 accumulator (|sum| < 2^24 units
-//   of 2^-15).
+//   one workgroup per (image, head); K (int8) and V^T (bf16) staged in LDS; each wave owns 16-query
+//   blocks.  S^T = K . Q^T on v_mfma_i32_16x16x64_i8 (one instruction covers head_dim 64) puts a score row
+//   on the 4 lanes {q, q+16, q+32, q+48}: 4 keys per 16-key block per lane, so the row max and the exact
+//   int64 sum of exp_int = z * 2^(32-q) are in-lane plus two cross-lane steps.  exp_int depends only on
+//   (max - score) in [0,255]: a 256-entry LDS table.  P = 2^-k is exact in bf16 and V codes are exact in
+//   bf16, so P.V on v_mfma_f32_16x16x32_bf16 is exact in its fp32 accumulator (|sum| < 2^24 units of 2^-15).
+//   The accumulator of S^T is already the B operand of the P.V product (k index = key): formal k = 8g+j of
+//   a 32-key step is key 4g+j (j<4) / 16+4g+(j-4) (j>=4); the V^T fragment is read with the same map.
+//   ~100 VGPRs -> 4 waves/SIMD, 3 workgroups (47 KB LDS each) per CU.
 // ---------------------------------------------------------------------------------------------------
-template <int HD, int NKB>
-__global__ __launch_bounds__(256) void k_lis_attention(AttnArgs a) {
-  constexpr int KROWS = NKB * 32;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int HD, int NKP, bool TAP>   // NKP = 32-key pairs covering the tokens (7 for 197); TAP: also write probs_k
+__global__ __launch_bounds__(256, 4) void k_lis_attention(AttnArgs a) {
+  constexpr int KROWS = NKP * 32;
+  constexpr int NKB = NKP * 2;                  // 16-key blocks
   constexpr int VSTRIDE = KROWS + 4;            // bf16 elements; dword stride = 2*odd -> conflict-free b64 reads
   constexpr int CH = HD / 16;                   // 16-byte chunks per K row
-  constexpr int NDT = HD / 32;                  // 32-wide output-channel tiles
-  constexpr int NKS = HD / 32;                  // int8 MFMA k-steps over head_dim
+  constexpr int NDT = HD / 16;                  // 16-wide output-channel tiles
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int8_t* sK = reinterpret_cast<int8_t*>(smem);                                  // [KROWS][HD] swizzled
   unsigned short* sVt = reinterpret_cast<unsigned short*>(smem + KROWS * HD);    // [HD][VSTRIDE] bf16
-  long long* lutE = reinterpret_cast<long long*>(smem + KROWS * HD + HD * VSTRIDE * 2);  // [256]
-  float* lutF = reinterpret_cast<float*>(lutE + 256);                             // [256]
+  long long* lutE = reinterpret_cast<long long*>(smem + KROWS * HD + HD * VSTRIDE * 2);  // [257]
+  float* lutF = reinterpret_cast<float*>(lutE + 258);                             // [257]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x / a.H, head = blockIdx.x % a.H;
   const int N = a.N, D = a.H * HD, ld = 3 * D;
   const int8_t* base = a.qkv + (long long)b * N * ld + head * HD;
 
   // exp table: d = max - score -> exp_int = z * 2^(32-q)       (int_exp / int_polynomial, layers.py:334-358)
+  // entry 256 is the sentinel of padded keys: contributes 0 to the sum and maps to probability 0.
   {
     int xi = -tid;
     const int lim = 32 * a.at.x0_int;
@@ -430,8 +667,12 @@ __global__ __launch_bounds__(256) void k_lis_attention(AttnArgs a) {
     e = e < 0 ? 0 : e;
     lutE[tid] = e;
     lutF[tid] = (float)e;                        // exact: z < 2^24
+    if (tid == 0) {
+      lutE[256] = 0;
+      lutF[256] = 1.0e-30f;                      // sum / 1e-30 -> +inf -> k clamps to 16 -> probability 0
+    }
   }
-  // stage K rows and V^T
+  // stage K rows (swizzled so that a 16-row x 16-byte-chunk fragment read is conflict free) and V^T (bf16)
   for (int i = tid; i < KROWS * CH; i += 256) {
     const int row = i / CH, c = i % CH;
     uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
@@ -439,7 +680,7 @@ __global__ __launch_bounds__(256) void k_lis_attention(AttnArgs a) {
       kv = *reinterpret_cast<const uint4*>(base + (long long)row * ld + D + c * 16);
       vv = *reinterpret_cast<const uint4*>(base + (long long)row * ld + 2 * D + c * 16);
     }
-    const int sw = (HD == 64) ? (c ^ ((row >> 2) & 3)) : (c ^ ((row >> 3) & 1));
+    const int sw = (HD == 64) ? (c ^ (((row >> 3) & 1) << 1)) : c;
     *reinterpret_cast<uint4*>(sK + row * HD + sw * 16) = kv;
     const unsigned w4[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
@@ -450,113 +691,100 @@ __global__ __launch_bounds__(256) void k_lis_attention(AttnArgs a) {
   }
   __syncthreads();
 
-  const int nqb = (N + 31) >> 5;
+  // (q@k^T)*scale / s_attn  ==  (acc * qk_scale) * (s_q1^2 / s_attn): the power-of-two factors commute with
+  // the single rounding of the *scale product (vit_fquant.py:316-317)
+  const float m1 = a.at.qk_scale, m2 = a.at.s_qkv_sq * a.at.inv_s_attn;
+  const int nqb = (N + 15) >> 4;
   for (int qb = wave; qb < nqb; qb += 4) {
-    const int qrow = qb * 32 + l31;
+    const int qrow = qb * 16 + l15;
     const int qr = qrow < N ? qrow : N - 1;
-    v4i fq[NKS];
+    v4i fq = {0, 0, 0, 0};
+    if (g < CH) fq = *reinterpret_cast<const v4i*>(base + (long long)qr * ld + g * 16);
+    v4i s[NKB];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-      fq[ks] = *reinterpret_cast<const v4i*>(base + (long long)qr * ld + ks * 32 + h * 16);
-    v16i s[NKB];
+    for (int kb = 0; kb < NKB; ++kb) {          // all score MFMAs first: no dependent use behind an MFMA
+      const int row = kb * 16 + l15, c = g & (CH - 1);
+      const int sw = (HD == 64) ? (c ^ (((row >> 3) & 1) << 1)) : c;
+      v4i fk = *reinterpret_cast<const v4i*>(sK + row * HD + sw * 16);
+      if (g >= CH) fk = (v4i){0, 0, 0, 0};
+      s[kb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq, (v4i){0, 0, 0, 0}, 0, 0, 0);
+    }
+    // scores -> int8 codes of qact_attn1 ; row max.  Padded keys (only in the last 32-key pair) get -1000.
+    int mx = -1000;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0;
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const int row = kb * 32 + l31, c = 2 * ks + h;
-        const int sw = (HD == 64) ? (c ^ ((row >> 2) & 3)) : (c ^ ((row >> 3) & 1));
-        const v4i fk = *reinterpret_cast<const v4i*>(sK + row * HD + sw * 16);
-        s[kb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fk, fq[ks], s[kb], 0, 0, 0);
+      for (int r = 0; r < 4; ++r) {
+        int c8 = sat8(((float)s[kb][r] * m1) * m2);
+        if (kb >= NKB - 2) c8 = (kb * 16 + 4 * g + r) < N ? c8 : -1000;
+        s[kb][r] = c8;
+        mx = c8 > mx ? c8 : mx;
       }
     }
-    // scores -> int8 codes of qact_attn1, row max           ((q@k^T)*scale -> QAct, vit_fquant.py:316-317)
-    int mx = -1000;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float f = (((float)s[kb][r] * a.at.s_qkv_sq) * a.at.qk_scale) * a.at.inv_s_attn;
-        const int c = key < N ? sat8(f) : -1000;
-        s[kb][r] = c;
-        mx = c > mx ? c : mx;
-      }
     {
-      const int o = __shfl_xor(mx, 32);
+      int o = __shfl_xor(mx, 16);
+      mx = o > mx ? o : mx;
+      o = __shfl_xor(mx, 32);
       mx = o > mx ? o : mx;
     }
     long long S = 0;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+    for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = s[kb][r];
-        const int d = c == -1000 ? -1 : mx - c;
+      for (int r = 0; r < 4; ++r) {
+        int d = mx - s[kb][r];
+        if (kb >= NKB - 2) d = d > 256 ? 256 : d;               // sentinel entry
         s[kb][r] = d;
-        S += d >= 0 ? lutE[d] : 0ll;
+        S += lutE[d];
       }
+      __builtin_amdgcn_sched_barrier(0);                         // keep live ranges short
+    }
+    S += __shfl_xor(S, 16);
     S += __shfl_xor(S, 32);
     const float Sf = (float)S;                                  // exp_int.sum(-1): exact, then one rounding
 
-    v16f o[NDT];
+    v4f o[NDT];
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
+    for (int dt = 0; dt < NDT; ++dt) o[dt] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    for (int p = 0; p < NKP; ++p) {
+      unsigned pk[4];
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      unsigned pk[8];
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
+      for (int e2 = 0; e2 < 4; ++e2) {
         unsigned hw2[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const int d = s[kb][r + e];
-          unsigned bits = 0;
-          int k = 16;
-          if (d >= 0) {
-            const float ratio = rintf(Sf / lutF[d]);            // round(sum / exp_int), layers.py:370
-            k = (int)((__float_as_uint(ratio) + 0x00400000u) >> 23) - 127;   // log_round, layers.py:323-329
-            k = k < 0 ? 0 : (k > 16 ? 16 : k);
-            bits = k < 16 ? (unsigned)(127 - k) << 7 : 0u;      // 2^-k as bf16; k>=16 -> 0 (layers.py:372-375)
-          }
-          hw2[e] = bits;
-          if (a.probs_k && d >= 0 && qrow < N) {
-            const int key = kb * 32 + ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * h;
-            a.probs_k[(((long long)b * a.H + head) * N + qrow) * N + key] = (int8_t)k;
-          }
+          const int j = 2 * e2 + e;                              // element of the 8-wide B fragment
+          const int kb = 2 * p + (j >> 2), r = j & 3;
+          const int d = s[kb][r];
+          const float ratio = rintf(Sf / lutF[d]);              // round(sum / exp_int), layers.py:370
+          int k = (int)((__float_as_uint(ratio) + 0x00400000u) >> 23) - 127;   // log_round, layers.py:323-329
+          k = k > 16 ? 16 : k;                                   // ratio >= 1, so k >= 0
+          hw2[e] = k < 16 ? (unsigned)(127 - k) << 7 : 0u;       // 2^-k as bf16; k>=16 -> 0 (layers.py:372-375)
+          if (TAP && d < 256 && qrow < N)
+            a.probs_k[(((long long)b * a.H + head) * N + qrow) * N + kb * 16 + 4 * g + r] = (int8_t)k;
         }
-        pk[r >> 1] = hw2[0] | (hw2[1] << 16);
+        pk[e2] = hw2[0] | (hw2[1] << 16);
       }
-      // O^T += V^T . P^T : A = V^T fragment (rows = channel), B = P^T (k = key, permuted as the accumulator
-      // rows come: element j of half h is key 16s + 8(j>>2) + 4h + (j&3)).
+      v4i pb = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+      const v8bf fb = __builtin_bit_cast(v8bf, pb);
 #pragma unroll
-      for (int sst = 0; sst < 2; ++sst) {
-        v4i pb = {(int)pk[4 * sst + 0], (int)pk[4 * sst + 1], (int)pk[4 * sst + 2], (int)pk[4 * sst + 3]};
-        const v8bf fb = __builtin_bit_cast(v8bf, pb);
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-          const unsigned short* vp = sVt + (dt * 32 + l31) * VSTRIDE + kb * 32 + 16 * sst + 4 * h;
-          const uint2 lo = *reinterpret_cast<const uint2*>(vp);
-          const uint2 hi = *reinterpret_cast<const uint2*>(vp + 8);
-          v4i va = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, va), fb, o[dt], 0, 0, 0);
-        }
+      for (int dt = 0; dt < NDT; ++dt) {
+        const unsigned short* vp = sVt + (dt * 16 + l15) * VSTRIDE + p * 32 + 4 * g;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
+        v4i va = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, va), fb, o[dt], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // qact2: (attn @ v) / s  with attn@v = O * s_q1   (vit_fquant.py:325-326)
+    // qact2: (attn @ v) / s  with attn@v = O * s_q1   (vit_fquant.py:325-326); lane owns channels 16dt+4g..+3
+    if (qrow < N) {
+      int8_t* dst = a.out + ((long long)b * N + qrow) * D + head * HD + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) {
-      unsigned dw[4];
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq)
-        dw[gq] = pack4(sat8(o[dt][4 * gq + 0] * a.at.av_mul), sat8(o[dt][4 * gq + 1] * a.at.av_mul),
-                       sat8(o[dt][4 * gq + 2] * a.at.av_mul), sat8(o[dt][4 * gq + 3] * a.at.av_mul));
-      const uint4 ov = halves_to_row16(dw[0], dw[1], dw[2], dw[3]);
-      if (qrow < N)
-        *reinterpret_cast<uint4*>(a.out + ((long long)b * N + qrow) * D + head * HD + dt * 32 + 16 * h) = ov;
+      for (int dt = 0; dt < NDT; ++dt)
+        *reinterpret_cast<unsigned*>(dst + dt * 16) =
+            pack4(sat8(o[dt][0] * a.at.av_mul), sat8(o[dt][1] * a.at.av_mul), sat8(o[dt][2] * a.at.av_mul), sat8(o[dt][3] * a.at.av_mul));
     }
   }
 }
@@ -602,6 +830,7 @@ __global__ __launch_bounds__(256) void k_gelu_err_sweep(unsigned first_bits, uns
 // ---------------------------------------------------------------------------------------------------
 // host launchers (called from the C ABI in p2vit_capi.cpp)
 // ---------------------------------------------------------------------------------------------------
+int g_use_panel = 0;   // P2V_GEMM_PANEL=1 selects the A-stationary panel kernel for K<=384 (A/B runs; measured slower: 1 block/CU)
 #define CHECK_LAUNCH()                                     \
   do {                                                     \
     hipError_t e_ = hipGetLastError();                     \
@@ -624,10 +853,50 @@ int p2v_launch_fill_cls(int8_t* x, int B, int T, int D, const int8_t* cls, hipSt
   return 0;
 }
 
+template <int EPI, int KP>
+static int launch_panel_t(const GemmArgs& g, int tiles_m, hipStream_t st) {
+  constexpr size_t smem = (size_t)3 * GBM * KP + 2 * sizeof(EpiLds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_panel<EPI, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  // tiles per work item: keep >= ~4 items per CU so the last round is well filled
+  int tpg = (int)(((long long)g.tiles_n * tiles_m) / 1024);
+  tpg = tpg < 1 ? 1 : (tpg > g.tiles_n ? g.tiles_n : tpg);
+  if (tpg > 4) tpg = 4;
+  const int groups = (g.tiles_n + tpg - 1) / tpg;
+  hipLaunchKernelGGL((k_gemm_panel<EPI, KP>), dim3(groups * tiles_m), dim3(512), smem, st, g, tpg);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+template <int EPI>
+static int launch_panel(const GemmArgs& g, int tiles_m, hipStream_t st) {
+  switch (g.K) {
+    case 64: return launch_panel_t<EPI, 64>(g, tiles_m, st);
+    case 192: return launch_panel_t<EPI, 192>(g, tiles_m, st);
+    case 256: return launch_panel_t<EPI, 256>(g, tiles_m, st);
+    case 384: return launch_panel_t<EPI, 384>(g, tiles_m, st);
+    default: return -2;
+  }
+}
+
 int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   GemmArgs g = g0;
   g.tiles_n = (g.N + GBN - 1) / GBN;
   const int tiles_m = (g.M + GBM - 1) / GBM;
+  if (g_use_panel && (g.K == 64 || g.K == 192 || g.K == 256 || g.K == 384) && g.lda == g.K) {
+    int rc = -2;
+    switch (epi) {
+      case P2V_EPI_REQUANT: rc = launch_panel<P2V_EPI_REQUANT>(g, tiles_m, st); break;
+      case P2V_EPI_GELU: rc = launch_panel<P2V_EPI_GELU>(g, tiles_m, st); break;
+      case P2V_EPI_RESID: rc = launch_panel<P2V_EPI_RESID>(g, tiles_m, st); break;
+      default: break;
+    }
+    if (rc != -2) return rc;
+  }
   dim3 grid(g.tiles_n * tiles_m), block(256);
   switch (epi) {
     case P2V_EPI_REQUANT: hipLaunchKernelGGL(k_gemm_i8<P2V_EPI_REQUANT>, grid, block, 0, st, g); break;
@@ -660,9 +929,12 @@ int p2v_launch_layernorm(const LnArgs& a, hipStream_t st) {
 
 template <int HD, int NKB>
 static int launch_attn_t(const AttnArgs& a, hipStream_t st) {
-  constexpr int KROWS = NKB * 32;
-  constexpr size_t smem = (size_t)KROWS * HD + (size_t)HD * (KROWS + 4) * 2 + 256 * 8 + 256 * 4;
-  hipLaunchKernelGGL((k_lis_attention<HD, NKB>), dim3(a.B * a.H), dim3(256), smem, st, a);
+  constexpr int KROWS = NKB * 32;   // NKB here = 32-key pairs
+  constexpr size_t smem = (size_t)KROWS * HD + (size_t)HD * (KROWS + 4) * 2 + 258 * 8 + 260 * 4;
+  if (a.probs_k)
+    hipLaunchKernelGGL((k_lis_attention<HD, NKB, true>), dim3(a.B * a.H), dim3(256), smem, st, a);
+  else
+    hipLaunchKernelGGL((k_lis_attention<HD, NKB, false>), dim3(a.B * a.H), dim3(256), smem, st, a);
   CHECK_LAUNCH();
   return 0;
 }
