@@ -51,12 +51,21 @@ static int bit_index(int bits) { return bits == 4 ? 0 : (bits == 8 ? 1 : -1); }
 extern "C" {
 
 extern int g_use_panel;
+extern int g_gemm_waves;
+extern int g_use_resident;
+extern int g_gemm_dbg;
 static void read_env_once() {
   static bool done = false;
   if (done) return;
   done = true;
   const char* e = getenv("P2V_GEMM_PANEL");
   if (e) g_use_panel = (e[0] == '1');
+  e = getenv("P2V_GEMM_RESIDENT");
+  if (e) g_use_resident = atoi(e);
+  e = getenv("P2V_GEMM_WAVES");
+  if (e) g_gemm_waves = atoi(e);
+  e = getenv("P2V_GEMM_DBG");
+  if (e) g_gemm_dbg = atoi(e);
 }
 int p2v_abi_version(void) { read_env_once(); return P2V_ABI_VERSION; }
 const char* p2v_last_error(void) { return g_err; }
@@ -172,7 +181,7 @@ static int run_gemm(int epi, const int8_t* A, int lda, int M, int K, int N, cons
                     int ldo, int8_t* out_codes, hipStream_t st) {
   GemmArgs g;
   g.A = A; g.lda = lda; g.M = M; g.W = lin.w_codes; g.K = K; g.N = N;
-  g.colscale = lin.colscale; g.bias = lin.bias; g.ep = ep; g.out = out; g.ldo = ldo; g.out_codes = out_codes; g.tiles_n = 0;
+  g.colscale = lin.colscale; g.bias = lin.bias; g.ep = ep; g.out = out; g.ldo = ldo; g.out_codes = out_codes; g.tiles_n = 0; g.dbg = 0;
   return launch_rc(p2v_launch_gemm(epi, g, st), "gemm_i8");
 }
 

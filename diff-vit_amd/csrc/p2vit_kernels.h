@@ -19,6 +19,7 @@ struct GemmArgs {
   int ldo;
   int8_t* out_codes;
   int tiles_n;          // filled by the launcher
+  int dbg;              // ablation switches (P2V_GEMM_DBG): 1 skip k-loop, 2 skip epilogue arithmetic, 4 skip stores
 };
 
 struct LnArgs {

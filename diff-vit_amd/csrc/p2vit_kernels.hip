@@ -293,6 +293,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
       }
     }
     d[gq] = pack4(q[0], q[1], q[2], q[3]);
+    if (EPI == P2V_EPI_RESID || EPI == P2V_EPI_EMBED) __builtin_amdgcn_sched_barrier(0);   // keep the constant reads of the next group from being hoisted (register pressure)
   }
   if (EPI != P2V_EPI_HEAD) {
     uint4 o = halves_to_row16(d[0], d[1], d[2], d[3]);
@@ -301,8 +302,108 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
   }
 }
 
+// one k-tile of MFMA work for a wave: 2 k-steps x (1 weight frag, 2 activation frags, 2 MFMAs)
+__device__ __forceinline__ void gemm_compute_tile(const int8_t* cx, const int8_t* cw, int wm, int wn, int l31, int h, v16i (&acc)[2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const v4i fw = *reinterpret_cast<const v4i*>(cw + lds_off64(wn * 32 + l31, 2 * ks + h));
+    const v4i f0 = *reinterpret_cast<const v4i*>(cx + lds_off64(wm * 64 + l31, 2 * ks + h));
+    const v4i f1 = *reinterpret_cast<const v4i*>(cx + lds_off64(wm * 64 + 32 + l31, 2 * ks + h));
+    acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw, f0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw, f1, acc[1], 0, 0, 0);
+  }
+}
+
+// Generic tiled GEMM: 128x128 block tile, 8 waves (2 along m x 4 along n, 64x32 each).  The fp32 epilogues are
+// dependent VALU chains: the measured issue rate of such chains on gfx950 is ~4.2 cycles/instruction at 2 waves
+// per SIMD and ~2.1 at 4 (tools/ubench/valu_rate.hip), so the kernel is shaped for <= 128 VGPRs -> 2 workgroups
+// (16 waves) per CU.  Global->LDS staging goes through a 3-deep ring of NAMED registers (an indexed array of
+// prefetch registers is placed in scratch by hipcc: measured), one barrier per k-tile.
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void k_gemm_i8(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) int8_t lds[2 * (GBM + GBN) * GBK + sizeof(EpiLds)];
+  int8_t* sX = lds;                    // [2][GBM][GBK] activation rows
+  int8_t* sW = lds + 2 * GBM * GBK;    // [2][GBN][GBK] weight rows
+  EpiLds* sE = reinterpret_cast<EpiLds*>(lds + 2 * (GBM + GBN) * GBK);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 2, wn = wave & 3;
+  // XCD-aware tile order: each XCD walks a contiguous range of tiles, n fastest, so the tiles that share
+  // an activation panel hit the same L2.
+  int bid = blockIdx.x, nt = gridDim.x, xcd = bid & 7, qd = nt >> 3, rm = nt & 7;
+  int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  const int tn = t % g.tiles_n, tm = t / g.tiles_n;
+  const int m0 = tm * GBM, n0 = tn * GBN;
+
+  const int lrow = tid >> 2, lchunk = tid & 3;      // 512 threads: one 16-byte chunk of each operand per k-tile
+  int mr0 = m0 + lrow;
+  mr0 = mr0 < g.M ? mr0 : g.M - 1;
+  const int8_t* gx0 = g.A + (long long)mr0 * g.lda + lchunk * 16;
+  const int8_t* gw0 = g.W + (long long)(n0 + lrow) * g.K + lchunk * 16;
+  const int o0 = lds_off64(lrow, lchunk);
+
+  v16i acc[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0;
+
+  const int nk = g.K / GBK;
+  uint4 ax0, aw0, bx0, bw0, cx0, cw0;
+#define G_LOAD(P, T)                                                        \
+  do {                                                                      \
+    P##x0 = *reinterpret_cast<const uint4*>(gx0 + (T) * GBK);               \
+    P##w0 = *reinterpret_cast<const uint4*>(gw0 + (T) * GBK);               \
+  } while (0)
+#define G_STEP(P, T)                                                        \
+  do {                                                                      \
+    int8_t* bx_ = sX + ((T) & 1) * GBM * GBK;                               \
+    int8_t* bw_ = sW + ((T) & 1) * GBN * GBK;                               \
+    *reinterpret_cast<uint4*>(bx_ + o0) = P##x0;                            \
+    *reinterpret_cast<uint4*>(bw_ + o0) = P##w0;                            \
+    __syncthreads();                                                        \
+    if ((T) + 3 < nk) G_LOAD(P, (T) + 3);                                   \
+    gemm_compute_tile(bx_, bw_, wm, wn, l31, h, acc);                       \
+  } while (0)
+  G_LOAD(a, 0);
+  if (nk > 1) G_LOAD(b, 1);
+  if (nk > 2) G_LOAD(c, 2);
+  gemm_stage_epilogue<EPI>(sE, n0, tid, g);        // visible after the first barrier of the k loop
+  if (g.dbg & 1) __syncthreads();
+  uint4 resv[2];                                   // residual codes of this lane's 2 output tiles, requested early
+  if (EPI == P2V_EPI_RESID) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 32 + 16 * h;
+      resv[mi] = make_uint4(0, 0, 0, 0);
+      if (m < g.M && n < g.N) resv[mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
+    }
+  }
+  for (int kt = 0; kt < ((g.dbg & 1) ? 0 : nk); kt += 3) {
+    G_STEP(a, kt);
+    if (kt + 1 < nk) G_STEP(b, kt + 1);
+    if (kt + 2 < nk) G_STEP(c, kt + 2);
+  }
+#undef G_LOAD
+#undef G_STEP
+  if (g.dbg & 2) {   // ablation: raw accumulator bytes, no fp32 arithmetic
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 32 + 16 * h;
+      uint4 o = make_uint4(acc[mi][0], acc[mi][4], acc[mi][8], acc[mi][12]);
+      if (!(g.dbg & 4) && m < g.M && n < g.N && EPI != P2V_EPI_HEAD)
+        *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)m * g.ldo + n) = o;
+    }
+    return;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+    gemm_epilogue_tile<EPI>(acc[mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 32, wn * 32, h, g, sE,
+                            EPI == P2V_EPI_RESID ? resv[mi] : make_uint4(0, 0, 0, 0));
+}
+
 // one k-tile of MFMA work for a wave: 2 k-steps x (2 weight frags, 2 activation frags, 4 MFMAs)
-__device__ __forceinline__ void gemm_compute_tile(const int8_t* cx, const int8_t* cw, int wm, int wn, int l31, int h, v16i (&acc)[2][2]) {
+__device__ __forceinline__ void gemm_compute_tile_w4(const int8_t* cx, const int8_t* cw, int wm, int wn, int l31, int h, v16i (&acc)[2][2]) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     v4i fw[2], fx[2];
@@ -319,11 +420,13 @@ __device__ __forceinline__ void gemm_compute_tile(const int8_t* cx, const int8_t
   }
 }
 
-// Generic tiled GEMM.  Global->LDS staging goes through a 3-deep ring of NAMED registers (an indexed array
+// 4-wave variant of the tiled GEMM (2x2 waves of 64x64, <=168 VGPRs, 3 workgroups per CU): measured 4-10 % faster
+// than the 8-wave shape on fc1/qkv at batch 256, so it is the default (P2V_GEMM_WAVES=8 selects the other).
+// Global->LDS staging goes through a 3-deep ring of NAMED registers (an indexed array
 // of prefetch registers is placed in scratch by hipcc: measured, 80 B private segment and a scratch round trip
 // per k-tile): tile t+3 is requested while tile t is computed, one barrier per k-tile.
 template <int EPI>
-__global__ __launch_bounds__(256, EPI == P2V_EPI_RESID ? 2 : 3) void k_gemm_i8(GemmArgs g) {
+__global__ __launch_bounds__(256, EPI == P2V_EPI_RESID ? 2 : 3) void k_gemm_i8_w4(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) int8_t lds[2 * (GBM + GBN) * GBK + sizeof(EpiLds)];
   int8_t* sX = lds;                    // [2][GBM][GBK] activation rows
   int8_t* sW = lds + 2 * GBM * GBK;    // [2][GBN][GBK] weight rows
@@ -375,12 +478,13 @@ __global__ __launch_bounds__(256, EPI == P2V_EPI_RESID ? 2 : 3) void k_gemm_i8(G
     *reinterpret_cast<uint4*>(bw_ + o1) = P##w1;                            \
     __syncthreads();                                                        \
     if ((T) + 3 < nk) G_LOAD(P, (T) + 3);                                   \
-    gemm_compute_tile(bx_, bw_, wm, wn, l31, h, acc);                       \
+    gemm_compute_tile_w4(bx_, bw_, wm, wn, l31, h, acc);                       \
   } while (0)
   G_LOAD(a, 0);
   if (nk > 1) G_LOAD(b, 1);
   if (nk > 2) G_LOAD(c, 2);
   gemm_stage_epilogue<EPI>(sE, n0, tid, g);        // visible after the first barrier of the k loop
+  if (g.dbg & 1) __syncthreads();
   uint4 resv[2][2];                                // residual codes of this lane's 4 output tiles, requested early
   if (EPI == P2V_EPI_RESID) {
 #pragma unroll
@@ -392,7 +496,7 @@ __global__ __launch_bounds__(256, EPI == P2V_EPI_RESID ? 2 : 3) void k_gemm_i8(G
         if (m < g.M && n < g.N) resv[ni][mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
       }
   }
-  for (int kt = 0; kt < nk; kt += 3) {
+  for (int kt = 0; kt < ((g.dbg & 1) ? 0 : nk); kt += 3) {
     G_STEP(a, kt);
     if (kt + 1 < nk) G_STEP(b, kt + 1);
     if (kt + 2 < nk) G_STEP(c, kt + 2);
@@ -530,6 +634,136 @@ __global__ __launch_bounds__(512, 2) void k_gemm_panel(GemmArgs g, int tpg) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K1c: persistent "resident" GEMM for K = 384 (qkv, fc1, proj of DeiT-S).
+//   Measured on the tiled kernel: time = (launch + first loads + stores) + k-loop + epilogue, strictly additive
+//   -- co-resident workgroups start together and stay in lock-step, so one block's loads never overlap another
+//   block's arithmetic.  Here the overlap is explicit: a block owns a contiguous range of 256x128 output tiles
+//   (n fastest, so the 256-row activation panel is reused from LDS across the n-tiles of a row panel), keeps
+//   BOTH whole-K operands of a tile in LDS (144 KB), and requests the operands of tile t+1 in four slices
+//   that ride under the four epilogue sub-tiles of tile t (the epilogue is the long, VALU-bound phase).
+//   8 waves (2 per SIMD), wave tile 64x64, one workgroup per CU, grid = #CUs.
+// ---------------------------------------------------------------------------------------------------
+#define RBM 256
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void k_gemm_resident(GemmArgs g, int tiles_total, int tiles_per_block) {
+  constexpr int KP = 384, NKT = KP / GBK, CPR = KP / 16;      // k-tiles, 16-byte chunks per row
+  constexpr int ATILE = RBM * GBK, WTILE = GBN * GBK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+  int8_t* sA = reinterpret_cast<int8_t*>(rsm);                 // [NKT][256][64] swizzled
+  int8_t* sW = sA + NKT * ATILE;                                // [NKT][128][64] swizzled
+  EpiLds* sE = reinterpret_cast<EpiLds*>(sW + NKT * WTILE);     // [2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int t_begin = blockIdx.x * tiles_per_block;
+  int t_end = t_begin + tiles_per_block;
+  t_end = t_end < tiles_total ? t_end : tiles_total;
+  if (t_begin >= t_end) return;
+
+  // element (row, chunk) of load slot c for this thread: e = tid + 512*c
+#define R_A_ADDR(c, mp_)                                                                      \
+  (g.A + (long long)((mp_) * RBM + (tid + 512 * (c)) / CPR < g.M ? (mp_) * RBM + (tid + 512 * (c)) / CPR : g.M - 1) * g.lda + \
+   ((tid + 512 * (c)) % CPR) * 16)
+#define R_W_ADDR(c, tn_) (g.W + (long long)((tn_) * GBN + (tid + 512 * (c)) / CPR) * g.K + ((tid + 512 * (c)) % CPR) * 16)
+#define R_A_LDS(c) (sA + (((tid + 512 * (c)) % CPR) >> 2) * ATILE + lds_off64((tid + 512 * (c)) / CPR, ((tid + 512 * (c)) % CPR) & 3))
+#define R_W_LDS(c) (sW + (((tid + 512 * (c)) % CPR) >> 2) * WTILE + lds_off64((tid + 512 * (c)) / CPR, ((tid + 512 * (c)) % CPR) & 3))
+  {
+    const int mp = t_begin / g.tiles_n, tn = t_begin % g.tiles_n;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) *reinterpret_cast<uint4*>(R_A_LDS(c)) = *reinterpret_cast<const uint4*>(R_A_ADDR(c, mp));
+#pragma unroll
+    for (int c = 0; c < 6; ++c) *reinterpret_cast<uint4*>(R_W_LDS(c)) = *reinterpret_cast<const uint4*>(R_W_ADDR(c, tn));
+    gemm_stage_epilogue<EPI>(&sE[0], tn * GBN, tid, g);
+  }
+  __syncthreads();
+
+  for (int t = t_begin, it = 0; t < t_end; ++t, ++it) {
+    const int mp = t / g.tiles_n, tn = t % g.tiles_n;
+    const int m0 = mp * RBM, n0 = tn * GBN;
+    const bool more = t + 1 < t_end;
+    const int mp2 = more ? (t + 1) / g.tiles_n : mp, tn2 = more ? (t + 1) % g.tiles_n : tn;
+    const bool newA = more && mp2 != mp;
+    uint4 resv[2][2];
+    if (EPI == P2V_EPI_RESID) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 64 + ni * 32 + 16 * h;
+          resv[ni][mi] = make_uint4(0, 0, 0, 0);
+          if (m < g.M && n < g.N) resv[ni][mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
+        }
+    }
+    v16i acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        v4i fw[2], fx[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fw[i] = *reinterpret_cast<const v4i*>(sW + kt * WTILE + lds_off64(wn * 64 + i * 32 + l31, 2 * ks + h));
+          fx[i] = *reinterpret_cast<const v4i*>(sA + kt * ATILE + lds_off64(wm * 64 + i * 32 + l31, 2 * ks + h));
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[ni], fx[mi], acc[ni][mi], 0, 0, 0);
+      }
+    }
+    __syncthreads();          // every wave has read its fragments: the operand buffers may be overwritten
+
+    // The operands of tile t+1 go global -> LDS by LDS-DMA (no VGPRs): every request is issued here, flies under
+    // the whole epilogue of tile t, and is retired by the vmcnt(0) that __syncthreads() carries.  An LDS-DMA
+    // wave-instruction writes 64 x 16 B linearly (16 rows of a [rows][64] sub-tile), so the XOR swizzle is
+    // applied to the per-lane SOURCE address: slot (row, pc) receives logical chunk pc ^ ((row>>2)&3).
+    if (more) {
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      const int lr = lane >> 2, pc = lane & 3;
+      if (newA) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int jj = wv + 8 * i, rb = jj & 15, kt = jj >> 4;
+          const int row = rb * 16 + lr;
+          int mr = mp2 * RBM + row;
+          mr = mr < g.M ? mr : g.M - 1;
+          const int8_t* src = g.A + (long long)mr * g.lda + kt * GBK + ((pc ^ ((row >> 2) & 3)) << 4);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(sA + kt * ATILE + rb * 16 * GBK), 16, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int jj = wv + 8 * i, rb = jj & 7, kt = jj >> 3;
+        const int row = rb * 16 + lr;
+        const int8_t* src = g.W + (long long)(tn2 * GBN + row) * g.K + kt * GBK + ((pc ^ ((row >> 2) & 3)) << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sW + kt * WTILE + rb * 16 * GBK), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        gemm_epilogue_tile<EPI>(acc[ni][mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, &sE[it & 1],
+                                EPI == P2V_EPI_RESID ? resv[ni][mi] : make_uint4(0, 0, 0, 0));
+    if (more) gemm_stage_epilogue<EPI>(&sE[(it + 1) & 1], tn2 * GBN, tid, g);
+    __syncthreads();
+  }
+#undef R_A_ADDR
+#undef R_W_ADDR
+#undef R_A_LDS
+#undef R_W_LDS
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K2: integer LayerNorm (QIntLayerNorm mode 'int', layers.py:255-289) + /channel_scale + qact0 clamp
 // (vit_fquant.py:284-289).  One row per 32-lane half wave (12 bytes/lane at C=384), LN_ROWS rows per half
 // wave so the five per-channel constant vectors stay in registers.  sum x and sum x^2 are exact integers;
@@ -637,7 +871,7 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <int HD, int NKP, bool TAP>   // NKP = 32-key pairs covering the tokens (7 for 197); TAP: also write probs_k
-__global__ __launch_bounds__(256, 4) void k_lis_attention(AttnArgs a) {
+__global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
   constexpr int KROWS = NKP * 32;
   constexpr int NKB = NKP * 2;                  // 16-key blocks
   constexpr int VSTRIDE = KROWS + 4;            // bf16 elements; dword stride = 2*odd -> conflict-free b64 reads
@@ -656,7 +890,7 @@ __global__ __launch_bounds__(256, 4) void k_lis_attention(AttnArgs a) {
 
   // exp table: d = max - score -> exp_int = z * 2^(32-q)       (int_exp / int_polynomial, layers.py:334-358)
   // entry 256 is the sentinel of padded keys: contributes 0 to the sum and maps to probability 0.
-  {
+  if (tid < 256) {
     int xi = -tid;
     const int lim = 32 * a.at.x0_int;
     xi = xi < lim ? lim : xi;
@@ -673,7 +907,7 @@ __global__ __launch_bounds__(256, 4) void k_lis_attention(AttnArgs a) {
     }
   }
   // stage K rows (swizzled so that a 16-row x 16-byte-chunk fragment read is conflict free) and V^T (bf16)
-  for (int i = tid; i < KROWS * CH; i += 256) {
+  for (int i = tid; i < KROWS * CH; i += 512) {
     const int row = i / CH, c = i % CH;
     uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
     if (row < N) {
@@ -695,7 +929,7 @@ __global__ __launch_bounds__(256, 4) void k_lis_attention(AttnArgs a) {
   // the single rounding of the *scale product (vit_fquant.py:316-317)
   const float m1 = a.at.qk_scale, m2 = a.at.s_qkv_sq * a.at.inv_s_attn;
   const int nqb = (N + 15) >> 4;
-  for (int qb = wave; qb < nqb; qb += 4) {
+  for (int qb = wave; qb < nqb; qb += 8) {
     const int qrow = qb * 16 + l15;
     const int qr = qrow < N ? qrow : N - 1;
     v4i fq = {0, 0, 0, 0};
@@ -830,6 +1064,9 @@ __global__ __launch_bounds__(256) void k_gelu_err_sweep(unsigned first_bits, uns
 // ---------------------------------------------------------------------------------------------------
 // host launchers (called from the C ABI in p2vit_capi.cpp)
 // ---------------------------------------------------------------------------------------------------
+int g_gemm_dbg = 0;
+int g_gemm_waves = 4;     // P2V_GEMM_WAVES=8: 8-wave (64x32 wave tile, <=128 VGPR) shape of the tiled kernel
+int g_use_resident = 0;   // P2V_GEMM_RESIDENT=0: tiled kernel everywhere (A/B runs)
 int g_use_panel = 0;   // P2V_GEMM_PANEL=1 selects the A-stationary panel kernel for K<=384 (A/B runs; measured slower: 1 block/CU)
 #define CHECK_LAUNCH()                                     \
   do {                                                     \
@@ -883,10 +1120,43 @@ static int launch_panel(const GemmArgs& g, int tiles_m, hipStream_t st) {
   }
 }
 
+template <int EPI>
+static int launch_resident(const GemmArgs& g, hipStream_t st) {
+  constexpr size_t smem = (size_t)(RBM + GBN) * 384 + 2 * sizeof(EpiLds);
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_resident<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorUnknown;
+    n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int tiles_total = g.tiles_n * ((g.M + RBM - 1) / RBM);
+  int blocks = n_cu < tiles_total ? n_cu : tiles_total;
+  const int tpb = (tiles_total + blocks - 1) / blocks;
+  blocks = (tiles_total + tpb - 1) / tpb;
+  hipLaunchKernelGGL((k_gemm_resident<EPI>), dim3(blocks), dim3(512), smem, st, g, tiles_total, tpb);
+  CHECK_LAUNCH();
+  return 0;
+}
+
 int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   GemmArgs g = g0;
+  g.dbg = g_gemm_dbg;
   g.tiles_n = (g.N + GBN - 1) / GBN;
   const int tiles_m = (g.M + GBM - 1) / GBM;
+  // resident kernel: K == 384, enough tiles to give every CU a few (else the tiled kernel's finer grain wins)
+  if (g_use_resident && g.K == 384 && g.lda == 384 && (long long)g.tiles_n * ((g.M + RBM - 1) / RBM) >= 512 && g.N % GBN == 0) {
+    switch (epi) {
+      case P2V_EPI_REQUANT: return launch_resident<P2V_EPI_REQUANT>(g, st);
+      case P2V_EPI_GELU: return launch_resident<P2V_EPI_GELU>(g, st);
+      case P2V_EPI_RESID: if (g_use_resident != 3) return launch_resident<P2V_EPI_RESID>(g, st); break;
+      default: break;
+    }
+  }
   if (g_use_panel && (g.K == 64 || g.K == 192 || g.K == 256 || g.K == 384) && g.lda == g.K) {
     int rc = -2;
     switch (epi) {
@@ -897,7 +1167,17 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
     }
     if (rc != -2) return rc;
   }
-  dim3 grid(g.tiles_n * tiles_m), block(256);
+  if (g_gemm_waves == 4 && epi != P2V_EPI_HEAD && epi != P2V_EPI_EMBED) {
+    dim3 grid4(g.tiles_n * tiles_m), block4(256);
+    switch (epi) {
+      case P2V_EPI_REQUANT: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_REQUANT>, grid4, block4, 0, st, g); break;
+      case P2V_EPI_GELU: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_GELU>, grid4, block4, 0, st, g); break;
+      default: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_RESID>, grid4, block4, 0, st, g); break;
+    }
+    CHECK_LAUNCH();
+    return 0;
+  }
+  dim3 grid(g.tiles_n * tiles_m), block(512);
   switch (epi) {
     case P2V_EPI_REQUANT: hipLaunchKernelGGL(k_gemm_i8<P2V_EPI_REQUANT>, grid, block, 0, st, g); break;
     case P2V_EPI_GELU: hipLaunchKernelGGL(k_gemm_i8<P2V_EPI_GELU>, grid, block, 0, st, g); break;
@@ -932,9 +1212,9 @@ static int launch_attn_t(const AttnArgs& a, hipStream_t st) {
   constexpr int KROWS = NKB * 32;   // NKB here = 32-key pairs
   constexpr size_t smem = (size_t)KROWS * HD + (size_t)HD * (KROWS + 4) * 2 + 258 * 8 + 260 * 4;
   if (a.probs_k)
-    hipLaunchKernelGGL((k_lis_attention<HD, NKB, true>), dim3(a.B * a.H), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((k_lis_attention<HD, NKB, true>), dim3(a.B * a.H), dim3(512), smem, st, a);
   else
-    hipLaunchKernelGGL((k_lis_attention<HD, NKB, false>), dim3(a.B * a.H), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((k_lis_attention<HD, NKB, false>), dim3(a.B * a.H), dim3(512), smem, st, a);
   CHECK_LAUNCH();
   return 0;
 }

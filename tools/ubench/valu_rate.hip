@@ -1,0 +1,60 @@
+// VALU issue-rate micro-benchmark for gfx950: cycles per wave64 instruction for plain / packed fp32 ops and the
+// conversion/rounding ops the requant epilogues are made of, at 1, 2, 4 waves per SIMD.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define ITER 2048
+template <int OP>
+__global__ void k(float* out, float a, float b, int n) {
+  float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+  f2 p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7}, pa = {a, a}, pb = {b, b};
+  long long t0 = clock64();
+  for (int i = 0; i < n; ++i) {
+    if (OP == 0) {  // 8 independent v_fma_f32
+      x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b);
+      x4 = __builtin_fmaf(x4, a, b); x5 = __builtin_fmaf(x5, a, b); x6 = __builtin_fmaf(x6, a, b); x7 = __builtin_fmaf(x7, a, b);
+    } else if (OP == 1) {  // 4 independent v_pk_fma_f32 (8 values)
+      p0 = __builtin_elementwise_fma(p0, pa, pb); p1 = __builtin_elementwise_fma(p1, pa, pb);
+      p2 = __builtin_elementwise_fma(p2, pa, pb); p3 = __builtin_elementwise_fma(p3, pa, pb);
+    } else if (OP == 2) {  // rndne
+      x0 = rintf(x0 * a); x1 = rintf(x1 * a); x2 = rintf(x2 * a); x3 = rintf(x3 * a);
+      x4 = rintf(x4 * a); x5 = rintf(x5 * a); x6 = rintf(x6 * a); x7 = rintf(x7 * a);
+    } else if (OP == 3) {  // exp2 (transcendental)
+      x0 = __builtin_amdgcn_exp2f(x0); x1 = __builtin_amdgcn_exp2f(x1); x2 = __builtin_amdgcn_exp2f(x2); x3 = __builtin_amdgcn_exp2f(x3);
+      x4 = __builtin_amdgcn_exp2f(x4); x5 = __builtin_amdgcn_exp2f(x5); x6 = __builtin_amdgcn_exp2f(x6); x7 = __builtin_amdgcn_exp2f(x7);
+    } else if (OP == 4) {  // cvt i32<->f32 pair
+      x0 = (float)((int)x0 + 1); x1 = (float)((int)x1 + 1); x2 = (float)((int)x2 + 1); x3 = (float)((int)x3 + 1);
+      x4 = (float)((int)x4 + 1); x5 = (float)((int)x5 + 1); x6 = (float)((int)x6 + 1); x7 = (float)((int)x7 + 1);
+    } else if (OP == 5) {  // packed mul
+      p0 = p0 * pa; p1 = p1 * pa; p2 = p2 * pa; p3 = p3 * pa;
+    }
+  }
+  long long t1 = clock64();
+  float s = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+  if (s == 12345.678f) out[0] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[1 + OP] = (float)(t1 - t0) / n;
+}
+template <int OP> void run(const char* name, int instr_per_iter, float* d) {
+  for (int wps = 1; wps <= 4; wps *= 2) {   // waves per SIMD: block of 256*wps threads, one block per CU
+    hipLaunchKernelGGL(k<OP>, dim3(256), dim3(256 * wps), 0, 0, d, 1.0001f, 0.5f, ITER);
+    hipDeviceSynchronize();
+    float h[8]; hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    printf("%-18s waves/SIMD=%d  clock64 ticks/iter=%.1f  -> %.2f ticks per wave-instruction (per wave); per SIMD %.2f\n", name, wps, h[1 + OP],
+           h[1 + OP] / instr_per_iter, h[1 + OP] / instr_per_iter / wps);
+  }
+}
+int main() {
+  float* d; hipMalloc(&d, 64); hipMemset(d, 0, 64);
+  run<0>("v_fma_f32 x8", 8, d); run<1>("v_pk_fma_f32 x4", 4, d); run<5>("v_pk_mul_f32 x4", 4, d);
+  run<2>("mul+rndne x8", 16, d); run<3>("v_exp_f32 x8", 8, d); run<4>("cvt,add,cvt x8", 24, d);
+  // wall-clock rate: fma
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int wps = 1; wps <= 4; wps *= 2) {
+    hipEventRecord(e0); for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(k<0>, dim3(256 * 4), dim3(256 * wps), 0, 0, d, 1.0001f, 0.5f, ITER * 8);
+    hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
+    double instr = 20.0 * 256 * 4 * (4 * wps) * ITER * 8 * 8;   // wave-instructions
+    printf("wall: fma waves/SIMD=%d: %.3f ms, %.3g wave-instr/s total, %.2f ns*SIMD per instr -> at 2.4GHz %.2f cycles\n", wps, ms, instr / (ms * 1e-3),
+           ms * 1e6 * 1024 / instr, ms * 1e-3 * 2.4e9 * 1024 / instr);
+  }
+  return 0;
+}
