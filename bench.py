@@ -72,9 +72,21 @@ def main():
 
     arch = dva.synth.ARCHS[MODEL]
     sd = dva.synth.vit_state_dict(arch, SEED)
-    # calibration state produced by the REAL reference on these weights (oracle/gen_golden.py)
-    calib = calib_io.load_npz(os.path.join(ROOT, 'tests', 'golden', 'deit_small.npz'))
-    plan = dva.FrozenPlan(arch, sd, calib, device=dev)
+    # the reference's flow through the drop-in surface: build, load, calibrate (float pass + observers, on the GPU),
+    # model_quant(); the first quantized forward freezes the integer plan.  Calibration batch = the one the REAL
+    # reference was calibrated on for tests/golden/deit_small.npz, so the resulting scales can be compared.
+    model = dva.deit_small_patch16_224(cfg=dva.Config(True, True, 'minmax'))
+    model.load_state_dict(sd, strict=False)
+    model = model.to(dev).eval()
+    t_cal = time.perf_counter()
+    dva.harness.calibrate_model(model, dva.synth.images(SEED, 2, arch['img_size']).to(dev))
+    torch.cuda.synchronize()
+    t_cal = time.perf_counter() - t_cal
+    calib = model.export_calib()
+    ref_calib = calib_io.flatten(calib_io.load_npz(os.path.join(ROOT, 'tests', 'golden', 'deit_small.npz')))
+    mine = calib_io.flatten(calib)
+    calib_same = all(torch.equal(mine[k].reshape(-1), ref_calib[k].reshape(-1)) for k in ref_calib)
+    plan = model.freeze(dev)
     B = args.batch
     # 32 distinct synthetic images per rank, tiled to the batch (content does not change the work)
     base = dva.synth.images(1000 + rank, min(B, 32), arch['img_size'])
@@ -84,7 +96,7 @@ def main():
     gathered = torch.empty(world * B, arch['num_classes'], device=dev) if world > 1 else None
 
     def step():
-        plan.forward(x, bits, out=logits)
+        plan.forward(x, bits, out=logits)          # == model(x, bits)[0] without the per-call Python list building
         if world > 1:
             dist.all_gather_into_tensor(gathered, logits)
 
@@ -169,6 +181,7 @@ def main():
             'model_mfma_frac': round(model_ops / (el / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
             'kernel_ms_per_step': breakdown,
             'cpu_baseline': cpu,
+            'calibration': {'seconds': round(t_cal, 2), 'device': 'gpu', 'scales_equal_reference': bool(calib_same)},
         }))
     if world > 1:
         dist.destroy_process_group()

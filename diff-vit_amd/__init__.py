@@ -1,5 +1,13 @@
-"""p2vit-mi355x: MI355X-native PoT-PTQ quantized ViT forward (drop-in for LeSN-Lab/diff-ViT's
-models/ptq + models/vit_fquant quantized inference path).  See DESIGN.md."""
-from . import synth  # noqa: F401
-from . import engine  # noqa: F401
+"""p2vit-mi355x: MI355X-native PoT-PTQ quantized ViT forward -- a drop-in for the quantized inference path of
+LeSN-Lab/diff-ViT (models/ptq + models/vit_fquant + config).  ``from diff_vit_amd import *`` yields what the
+reference's ``from models import *`` + ``from config import Config`` yield for this path.  See DESIGN.md."""
+from . import synth, engine, calib_io, dp, harness  # noqa: F401
+from .config import Config  # noqa: F401
 from .plan import FrozenPlan  # noqa: F401
+from .ptq import BIT_TYPE_DICT, QAct, QConv2d, QIntLayerNorm, QIntSoftmax, QLinear  # noqa: F401
+from .vit import (VisionTransformer, deit_base_patch16_224, deit_small_patch16_224, deit_tiny_patch16_224,  # noqa: F401
+                  vit_base_patch16_224, vit_large_patch16_224)
+
+__all__ = ['BIT_TYPE_DICT', 'QAct', 'QConv2d', 'QIntLayerNorm', 'QIntSoftmax', 'QLinear', 'Config', 'VisionTransformer',
+           'deit_tiny_patch16_224', 'deit_small_patch16_224', 'deit_base_patch16_224', 'vit_base_patch16_224',
+           'vit_large_patch16_224', 'FrozenPlan']

@@ -1,0 +1,52 @@
+"""Data-parallel execution of the quantized forward over the GPUs of one node.
+
+The path shards naturally: images are independent and every scale is frozen at calibration, so there is no
+cross-sample statistic.  One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI on ROCm; "gloo" in
+the CPU tests), the frozen plan is replicated, the global batch is split contiguously, and the only exchange step is one
+all-gather of the logits per batch: fp32 [B_local, classes] (1 MB per GPU at 256 x 1000) or, with
+``codes=True``, the int8 logit codes (4x smaller; logits are codes * act_out scale).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world, rank):
+    """contiguous split of n items; the first n % world ranks get one more."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+class DataParallelForward:
+    """``forward_fn(local_images) -> local_logits`` on every rank, then all-gather.  ``forward_fn`` is the product's
+    quantized forward on GPU ranks (``lambda x: model(x, bits)[0]``)."""
+
+    def __init__(self, forward_fn, num_classes, group=None):
+        self.fn = forward_fn
+        self.num_classes = num_classes
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def __call__(self, global_images):
+        """every rank passes the same global batch (or only its own slice via ``local``)."""
+        lo, hi = shard_bounds(global_images.shape[0], self.world, self.rank)
+        return self.local(global_images[lo:hi], global_images.shape[0])
+
+    def local(self, local_images, global_n):
+        out = self.fn(local_images)
+        if self.world == 1:
+            return out
+        sizes = [shard_bounds(global_n, self.world, r) for r in range(self.world)]
+        counts = [b - a for a, b in sizes]
+        if len(set(counts)) == 1:
+            gathered = torch.empty(global_n, self.num_classes, dtype=out.dtype, device=out.device)
+            dist.all_gather_into_tensor(gathered, out.contiguous(), group=self.group)
+            return gathered
+        # ragged global batch: collectives need equal shapes, so pad every shard to the largest one
+        cmax = max(counts)
+        padded = torch.zeros(cmax, self.num_classes, dtype=out.dtype, device=out.device)
+        padded[:out.shape[0]] = out
+        gathered = torch.empty(self.world * cmax, self.num_classes, dtype=out.dtype, device=out.device)
+        dist.all_gather_into_tensor(gathered, padded, group=self.group)
+        return torch.cat([gathered[r * cmax: r * cmax + counts[r]] for r in range(self.world)], 0)

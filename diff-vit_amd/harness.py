@@ -1,0 +1,187 @@
+"""Evaluation harness of the hot path: the counterpart of the reference driver's ``validate / accuracy /
+AverageMeter / seed / str2model`` and of its calibration sequence (test_quant.py:56-86,214-249,418-501).
+
+Differences the build owns: a synthetic-data mode (no ImageFolder / torchvision / network),
+``--mixed`` off by default (the reference's Hessian + Pareto search never completes as shipped, test_quant.py:186),
+and images/sec reporting.  Everything else -- flag names, model-name map, the calibration call order, unpacking three
+returns from ``model(data, bit_config, plot)``, top-k by ``output.topk(maxk, 1, True, True)`` and the print format --
+follows the reference.
+"""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import synth
+from .config import Config
+from . import vit
+
+
+def build_parser():
+    """same flags and defaults as test_quant.py:18-53 (plus --synthetic/--n-val for the offline mode)."""
+    p = argparse.ArgumentParser(description='P2-ViT PoT-PTQ on MI355X')
+    p.add_argument('--model', default='deit_tiny')
+    p.add_argument('--data', default='/home/ubuntu/imagenet')
+    p.add_argument('--quant', default=False, action='store_true')
+    p.add_argument('--ptf', default=True)
+    p.add_argument('--lis', default=True)
+    p.add_argument('--quant-method', default='minmax', choices=['minmax', 'ema', 'omse', 'percentile'])
+    p.add_argument('--mixed', default=False, action='store_true')
+    p.add_argument('--calib-batchsize', default=50, type=int, help='batchsize of calibration set')
+    p.add_argument('--mode', default=1, type=int, help='calibration data: 1 Gaussian noise (offline default), 0/2 need real data')
+    p.add_argument('--calib-iter', default=6, type=int)
+    p.add_argument('--val-batchsize', default=50, type=int, help='batchsize of validation set')
+    p.add_argument('--num-workers', default=16, type=int)
+    p.add_argument('--device', default='cuda', type=str, help='device')
+    p.add_argument('--print-freq', default=100, type=int, help='print frequency')
+    p.add_argument('--seed', default=0, type=int, help='seed')
+    p.add_argument('--synthetic', default=True, action='store_true', help='synthetic ImageNet-shaped data and random-init weights')
+    p.add_argument('--n-val', default=500, type=int, help='number of synthetic validation images')
+    p.add_argument('--bits', default=8, type=int, choices=[4, 8], help='uniform bit_config for the validation run')
+    return p
+
+
+def str2model(name):
+    """test_quant.py:56-68 (the Swin entries need the windowed-attention path: not built yet)."""
+    d = {'deit_tiny': vit.deit_tiny_patch16_224, 'deit_small': vit.deit_small_patch16_224,
+         'deit_base': vit.deit_base_patch16_224, 'vit_base': vit.vit_base_patch16_224,
+         'vit_large': vit.vit_large_patch16_224}
+    if name.startswith('swin'):
+        raise NotImplementedError('%s: the Swin graph is stale in the reference itself (no runnable oracle); not built' % name)
+    print('Model: %s' % name)
+    return d[name]
+
+
+def seed(seed=0):
+    """test_quant.py:71-86"""
+    os.environ['PYTHONHASHSEED'] = str(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+class AverageMeter(object):
+    """test_quant.py:469-485"""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def accuracy(output, target, topk=(1,)):
+    """precision@k (test_quant.py:488-501)"""
+    maxk = max(topk)
+    batch_size = target.size(0)
+    _, pred = output.topk(maxk, 1, True, True)
+    pred = pred.t()
+    correct = pred.eq(target.reshape(1, -1).expand_as(pred))
+    return [correct[:k].reshape(-1).float().sum(0).mul_(100.0 / batch_size) for k in topk]
+
+
+def calibrate_model(model, calibrate_data):
+    """the reference's calibration sequence (test_quant.py:235-249): one forward with calibrate + last_calibrate
+    open, then close and switch to quant."""
+    model.model_open_calibrate()
+    with torch.no_grad():
+        model.model_open_last_calibrate()
+        output, FLOPs, global_distance = model(calibrate_data, plot=False)
+    model.model_close_calibrate()
+    model.model_quant()
+    return output, FLOPs, global_distance
+
+
+class SyntheticLoader:
+    """ImageNet-shaped batches from the deterministic generator; labels = argmax of a float teacher pass are supplied
+    by the caller (there is no dataset offline), default labels are a fixed pseudo-random class per image."""
+
+    def __init__(self, n, batch_size, img_size=224, num_classes=1000, seed=0, device='cpu', targets=None):
+        self.n, self.bs, self.img, self.seed, self.device = n, batch_size, img_size, seed, device
+        self.targets = targets if targets is not None else torch.from_numpy(
+            (synth._stream(seed, 'labels', n) % np.uint64(num_classes)).astype(np.int64))
+
+    def __len__(self):
+        return (self.n + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        for i in range(0, self.n, self.bs):
+            k = min(self.bs, self.n - i)
+            yield synth.images(self.seed, k, self.img, offset=i).to(self.device), self.targets[i:i + k].to(self.device)
+
+
+def validate(args, val_loader, model, criterion, device, bit_config=None):
+    """test_quant.py:418-466; additionally returns images/sec of the forward calls."""
+    batch_time, losses, top1, top5 = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
+    model.eval()
+    val_start_time = end = time.time()
+    n_img, fwd = 0, 0.0
+    for i, (data, target) in enumerate(val_loader):
+        data = data.to(device)
+        target = target.to(device)
+        t0 = time.time()
+        with torch.no_grad():
+            output, FLOPs, distance = model(data, bit_config, False)
+        if data.is_cuda:
+            torch.cuda.synchronize()
+        fwd += time.time() - t0
+        n_img += data.size(0)
+        loss = criterion(output, target)
+        prec1, prec5 = accuracy(output.data, target, topk=(1, 5))
+        losses.update(loss.data.item(), data.size(0))
+        top1.update(prec1.data.item(), data.size(0))
+        top5.update(prec5.data.item(), data.size(0))
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if i % args.print_freq == 0:
+            print('Test: [{0}/{1}]\t'
+                  'Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
+                  'Loss {loss.val:.4f} ({loss.avg:.4f})\t'
+                  'Prec@1 {top1.val:.3f} ({top1.avg:.3f})\t'
+                  'Prec@5 {top5.val:.3f} ({top5.avg:.3f})'.format(i, len(val_loader), batch_time=batch_time, loss=losses,
+                                                                 top1=top1, top5=top5))
+    val_end_time = time.time()
+    print(' * Prec@1 {top1.avg:.3f} Prec@5 {top5.avg:.3f} Time {time:.3f}'.format(top1=top1, top5=top5,
+                                                                              time=val_end_time - val_start_time))
+    print(' * forward throughput %.1f images/sec' % (n_img / max(fwd, 1e-9)))
+    return losses.avg, top1.avg, top5.avg
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    seed(args.seed)
+    device = torch.device(args.device)
+    cfg = Config(args.ptf, args.lis, args.quant_method)
+    model = str2model(args.model)(pretrained=False, cfg=cfg)
+    arch = model.arch
+    model.load_state_dict(synth.vit_state_dict(arch, args.seed), strict=False)
+    model = model.to(device).eval()
+    # labels: the float model's own top-1 ("agreement with fp32"), the metric BASELINE.json names besides images/sec
+    loader = SyntheticLoader(args.n_val, args.val_batchsize, arch['img_size'], arch['num_classes'], args.seed, device)
+    with torch.no_grad():
+        tgt = torch.cat([model(d)[0].argmax(1).cpu() for d, _ in loader])
+    loader = SyntheticLoader(args.n_val, args.val_batchsize, arch['img_size'], arch['num_classes'], args.seed, device, tgt)
+    criterion = nn.CrossEntropyLoss().to(device)
+    bit_config = None
+    if args.quant:
+        print('Calibrating with Gaussian noise...')
+        calibrate_model(model, synth.images(args.seed + 1, args.calib_batchsize, arch['img_size']).to(device))
+        bit_config = [args.bits] * (4 * arch['depth'] + 2)
+        print(bit_config)
+    return validate(args, loader, model, criterion, device, bit_config)
+
+
+if __name__ == '__main__':
+    main()

@@ -263,3 +263,66 @@ def test_gelu_fast_path_bound_and_exactness(dva, oracle):
         assert torch.equal(fast, slow)
         assert torch.equal(slow.cpu().float(), ref), int((slow.cpu().float() != ref).sum())
         assert 0 < int(flags.item()) < y.numel() * 0.01
+
+
+# --------------------------------------------------------------------------------------------------
+# the drop-in flow: module surface -> calibrate -> model_quant -> forward (engine)
+# --------------------------------------------------------------------------------------------------
+def _build_micro(dva, micro):
+    from functools import partial
+    a = micro['arch']
+    m = dva.VisionTransformer(img_size=a['img_size'], patch_size=a['patch_size'], embed_dim=a['embed_dim'], depth=a['depth'],
+                              num_heads=a['num_heads'], num_classes=a['num_classes'], mlp_ratio=a['mlp_ratio'], qkv_bias=True,
+                              norm_layer=partial(dva.QIntLayerNorm, eps=1e-6), input_quant=True, cfg=dva.Config())
+    m.load_state_dict(micro['sd'], strict=False)
+    return m.eval()
+
+
+@pytest.mark.parametrize('calib_device', ['cpu', 'cuda'])
+def test_dropin_flow_matches_reference(dva, micro, calib_device):
+    """test_quant.py-shaped usage; calibration on the host or on the GPU gives the reference's scales, and the
+    quantized forward (HIP engine) gives the reference's logits for all three bit configurations."""
+    g = micro['g']
+    m = _build_micro(dva, micro).to(calib_device)
+    out_cal, _, gd = dva.harness.calibrate_model(m, micro['x_cal'].to(calib_device))
+    flat = dva.calib_io.flatten(m.export_calib())
+    for k, v in flat.items():
+        assert np.array_equal(v.numpy().reshape(g['calib/' + k].shape), g['calib/' + k]), (calib_device, k)
+    m = m.cuda()
+    for tag in ('q8', 'q4', 'qmix'):
+        out, flops, gd2 = m(micro['x_ev'].cuda(), _bits(g, tag, 10), False)
+        assert np.array_equal(out.cpu().numpy(), g['logits/' + tag]), tag
+        assert flops == [int(v) for v in g['flops']] and gd2 == []
+    with pytest.raises(ValueError):
+        m(micro['x_ev'].cuda(), None)
+    with pytest.raises(NotImplementedError):
+        m(micro['x_ev'].cuda(), [8] * 9 + [-1])
+    # re-calibration invalidates the frozen plan
+    assert m._plan is not None
+    m.model_open_calibrate()
+    assert m._plan is None
+    m.model_close_calibrate()
+
+
+def test_module_level_quant_ops_on_gpu(dva):
+    """stand-alone QAct in quant state on a GPU tensor runs the HIP fake-quant kernel and equals the torch chain."""
+    q = dva.QAct(quant=True)
+    q.quantizer.scale = torch.tensor([2.0 ** -3])
+    q.quantizer.zero_point = torch.zeros(1, dtype=torch.int64)
+    x = dva.synth.normal(3, 'qact', (4, 17, 64), 9.0)
+    ref = torch.clamp(torch.round(x / 2.0 ** -3), -128, 127) * 2.0 ** -3
+    assert torch.equal(q(x.cuda()).cpu(), ref) and torch.equal(q(x), ref)
+    lin = dva.QLinear(64, 32, quant=True, bit_type=dva.BIT_TYPE_DICT['int4'])
+    lin.quantizer.dic_scale = {'int4': torch.full((32,), 2.0 ** -5), 'int8': torch.tensor([2.0 ** -8])}
+    lin.quantizer.dic_zero_point = {'int4': torch.zeros(32, dtype=torch.int64), 'int8': torch.zeros(1, dtype=torch.int64)}
+    y_cpu = lin(x, [], 4)
+    y_gpu = lin.cuda()(x.cuda(), [], 4).cpu()
+    assert (y_cpu - y_gpu).abs().max() < 1e-4
+
+
+def test_harness_main_synthetic(dva, capsys):
+    loss, top1, top5 = dva.harness.main(['--model', 'deit_tiny', '--quant', '--n-val', '24', '--val-batchsize', '8',
+                                          '--calib-batchsize', '2', '--print-freq', '1'])
+    out = capsys.readouterr().out
+    assert ' * Prec@1' in out and 'images/sec' in out and 'Calibrating with Gaussian noise' in out
+    assert 0.0 <= top1 <= 100.0

@@ -1,0 +1,142 @@
+"""CPU: the product's drop-in module surface (calibration + float path) against the REAL reference's outputs
+(tests/golden) -- identical scales/exponents, float pass bit-equal (north_star asks <= 1e-5)."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_calib, load_golden
+
+
+def _micro_model(dva, micro):
+    a = micro['arch']
+    m = dva.VisionTransformer(img_size=a['img_size'], patch_size=a['patch_size'], embed_dim=a['embed_dim'], depth=a['depth'],
+                              num_heads=a['num_heads'], num_classes=a['num_classes'], mlp_ratio=a['mlp_ratio'], qkv_bias=True,
+                              norm_layer=partial(dva.QIntLayerNorm, eps=1e-6), input_quant=True, cfg=dva.Config(True, True, 'minmax'))
+    missing, unexpected = m.load_state_dict(micro['sd'], strict=False)
+    assert not missing and not unexpected
+    return m.eval()
+
+
+@pytest.fixture(scope='module')
+def dva():
+    import diff_vit_amd
+    return diff_vit_amd
+
+
+def test_exports_match_reference_surface(dva):
+    for name in ('QAct', 'QConv2d', 'QLinear', 'QIntLayerNorm', 'QIntSoftmax', 'BIT_TYPE_DICT', 'Config', 'deit_tiny_patch16_224',
+                 'deit_small_patch16_224', 'deit_base_patch16_224', 'vit_base_patch16_224', 'vit_large_patch16_224'):
+        assert hasattr(dva, name), name
+    assert sorted(dva.BIT_TYPE_DICT) == ['int4', 'int8', 'uint3', 'uint4', 'uint8']
+    c = dva.Config()
+    assert c.BIT_TYPE_W.name == 'int4' and c.BIT_TYPE_A.name == 'int8' and c.BIT_TYPE_S.name == 'uint4'
+    assert c.OBSERVER_A_LN == 'ptf' and c.CALIBRATION_MODE_W == 'channel_wise' and c.INT_NORM and c.INT_SOFTMAX
+    q = dva.QLinear(8, 4)
+    for attr in ('quant', 'calibrate', 'last_calibrate', 'bit_type', 'observer', 'quantizer', 'module_type'):
+        assert hasattr(q, attr)
+    assert hasattr(q.quantizer, 'dic_scale') and hasattr(q.observer, 'max_val') and q.observer.symmetric
+    with pytest.raises(AssertionError):
+        dva.QIntLayerNorm((8,))
+
+
+def test_float_forward_and_flops(dva, micro):
+    m = _micro_model(dva, micro)
+    with torch.no_grad():
+        out, flops, gd = m(micro['x_ev'])
+    assert np.array_equal(out.numpy(), micro['g']['fp_logits'])
+    assert flops == [int(v) for v in micro['g']['flops']] and gd == []
+    assert flops == m.flops()
+
+
+def test_calibration_identical_to_reference(dva, micro):
+    g = micro['g']
+    m = _micro_model(dva, micro)
+    m.model_open_calibrate()
+    with torch.no_grad():
+        m.model_open_last_calibrate()
+        out, flops, gd = m(micro['x_cal'], plot=False)
+    m.model_close_calibrate()
+    m.model_quant()
+    assert np.abs(out.numpy() - g['calib_logits']).max() <= 1e-5
+    flat = dva.calib_io.flatten(m.export_calib())
+    assert len(flat) == sum(1 for k in g.files if k.startswith('calib/'))
+    for k, v in flat.items():
+        assert np.array_equal(v.numpy().reshape(g['calib/' + k].shape), g['calib/' + k]), k
+    gdn = np.array([[float(v) for v in row] for row in gd])
+    assert gdn.shape == g['global_distance'].shape and np.allclose(gdn, g['global_distance'], rtol=1e-5, atol=0)
+    # quantized forward has no CPU fallback
+    with pytest.raises(RuntimeError):
+        m(micro['x_ev'], [8] * 10)
+    with pytest.raises(ValueError):
+        m(micro['x_ev'], None)
+
+
+def test_module_level_ops_against_kats(dva):
+    g = load_golden('kat_ops')
+    for e in range(3, 9):
+        sm = dva.QIntSoftmax(log_i_softmax=True, bit_type=dva.BIT_TYPE_DICT['uint4'], quantizer_str='log2')
+        sf = torch.tensor([2.0 ** -e])
+        p = sm(torch.from_numpy(g['lis/%d/codes' % e]).float() * sf, sf)
+        assert np.array_equal(p.numpy(), g['lis/%d/probs' % e]), e
+    for tag in ('a', 'b'):
+        C = g['ln/%s/gamma' % tag].shape[0]
+        ln = dva.QIntLayerNorm(C)
+        ln.weight.data = torch.from_numpy(g['ln/%s/gamma' % tag]); ln.bias.data = torch.from_numpy(g['ln/%s/beta' % tag])
+        ln.mode = 'int'
+        class Q: pass
+        qi, qo = Q(), Q()
+        qi.scale = torch.from_numpy(g['ln/%s/in_scale' % tag]); qo.scale = torch.tensor([2.0 ** -4])
+        ex = int(g['ln/%s/expand' % tag])
+        full = qi.scale if ex == 1 else qi.scale.unsqueeze(-1).expand(-1, ex).T.reshape(-1)
+        cs = torch.from_numpy(g['ln/%s/out_scale' % tag]) / qo.scale
+        y = ln(torch.from_numpy(g['ln/%s/codes' % tag]).float() * full.reshape(1, 1, -1), qi, qo, cs, ex)
+        assert np.array_equal(y.detach().numpy(), g['ln/%s/out' % tag]), tag
+    M, N = dva.QIntLayerNorm(4).get_MN(torch.from_numpy(g['mn/A']))
+    assert np.array_equal(M.numpy(), g['mn/M']) and np.array_equal(N.numpy(), g['mn/N'])
+    from diff_vit_amd.ptq.observer import build_observer
+    xa = torch.from_numpy(g['mm/act/x'])
+    ob = build_observer('minmax', 'activation', dva.BIT_TYPE_DICT['int8'], 'layer_wise'); ob.update(xa)
+    assert np.array_equal(ob.get_quantization_params(xa)[0].numpy(), g['mm/act/scale'])
+    w, b = torch.from_numpy(g['mm/w']), torch.from_numpy(g['mm/b'])
+    ob = build_observer('minmax', 'linear_weight', dva.BIT_TYPE_DICT['int4'], 'channel_wise')
+    for bt in ('uint3', 'uint4', 'int4', 'int8'):
+        ob.bit_type = dva.BIT_TYPE_DICT[bt]; ob.calibration_mode = 'layer_wise' if bt == 'int8' else 'channel_wise'
+        ob.update(w)
+        s, _ = ob.get_quantization_params(xa, others=[b])
+        assert np.array_equal(s.numpy().reshape(g['mm/w/%s' % bt].shape), g['mm/w/%s' % bt]), bt
+    xp = torch.from_numpy(g['ptf/x'])
+    ob = build_observer('ptf', 'activation', dva.BIT_TYPE_DICT['int8'], 'channel_wise'); ob.update(xp)
+    assert np.array_equal(ob.get_quantization_params(xp)[0].numpy(), g['ptf/scale'])
+    from diff_vit_amd.ptq.quantizer import build_quantizer
+    x, s = torch.from_numpy(g['uq/x']), torch.from_numpy(g['uq/scale'])
+    for bt in ('int8', 'int4', 'uint4'):
+        qz = build_quantizer('uniform', dva.BIT_TYPE_DICT[bt], None, 'activation')
+        qz.scale, qz.zero_point = s, torch.zeros(16, dtype=torch.int64)
+        assert np.array_equal(qz(x).numpy(), g['uq/%s/out' % bt]), bt
+
+
+def test_deit_small_calibration_identical_to_reference(dva):
+    """full-size DeiT-S: the batched PoT search reproduces every one of the reference's 495 calibrated tensors,
+    the calibration-pass logits and the weight-MSE bookkeeping (global_distance) -- in ~2 s instead of ~1-2 min."""
+    g = load_golden('deit_small')
+    seed = int(g['seed'])
+    m = dva.deit_small_patch16_224(cfg=dva.Config(True, True, 'minmax'))
+    m.load_state_dict(dva.synth.vit_state_dict(dva.synth.ARCHS['deit_small'], seed), strict=False)
+    m.eval()
+    x = dva.synth.images(seed, int(g['n_calib']), 224)
+    m.model_open_calibrate()
+    with torch.no_grad():
+        m.model_open_last_calibrate()
+        out, flops, gd = m(x, plot=False)
+    m.model_close_calibrate()
+    m.model_quant()
+    assert np.abs(out.numpy() - g['calib_logits']).max() <= 1e-5
+    flat = dva.calib_io.flatten(m.export_calib())
+    assert len(flat) == sum(1 for k in g.files if k.startswith('calib/')) == 495
+    for k, v in flat.items():
+        assert np.array_equal(v.numpy().reshape(g['calib/' + k].shape), g['calib/' + k]), k
+    gdn = np.array([[float(v) for v in row] for row in gd])
+    assert np.allclose(gdn, g['global_distance'], rtol=1e-5, atol=0)
+    assert flops == [int(v) for v in g['flops']]
