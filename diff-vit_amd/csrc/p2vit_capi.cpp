@@ -52,6 +52,8 @@ extern "C" {
 
 extern int g_use_panel;
 extern int g_gemm_waves;
+extern unsigned long long* g_gemm_stamps;
+extern int g_gemm_stagger;
 extern int g_use_resident;
 extern int g_gemm_dbg;
 static void read_env_once() {
@@ -64,6 +66,8 @@ static void read_env_once() {
   if (e) g_use_resident = atoi(e);
   e = getenv("P2V_GEMM_WAVES");
   if (e) g_gemm_waves = atoi(e);
+  e = getenv("P2V_GEMM_STAGGER");
+  if (e) g_gemm_stagger = atoi(e);
   e = getenv("P2V_GEMM_DBG");
   if (e) g_gemm_dbg = atoi(e);
 }
@@ -181,7 +185,7 @@ static int run_gemm(int epi, const int8_t* A, int lda, int M, int K, int N, cons
                     int ldo, int8_t* out_codes, hipStream_t st) {
   GemmArgs g;
   g.A = A; g.lda = lda; g.M = M; g.W = lin.w_codes; g.K = K; g.N = N;
-  g.colscale = lin.colscale; g.bias = lin.bias; g.ep = ep; g.out = out; g.ldo = ldo; g.out_codes = out_codes; g.tiles_n = 0; g.dbg = 0;
+  g.colscale = lin.colscale; g.bias = lin.bias; g.ep = ep; g.out = out; g.ldo = ldo; g.out_codes = out_codes; g.tiles_n = 0; g.dbg = 0; g.stagger = 0; g.stamps = nullptr;
   return launch_rc(p2v_launch_gemm(epi, g, st), "gemm_i8");
 }
 
@@ -362,6 +366,9 @@ int p2v_gelu_quant_f32(const float* y, long long n, float inv_s, int8_t* codes, 
   if (n == 0) return P2V_OK;
   return launch_rc(p2v_launch_gelu_quant(y, n, inv_s, codes, flags, force_slow, (hipStream_t)stream), "gelu_quant");
 }
+
+/* debug only (not in the public header): device buffer receiving 6 x uint64 per workgroup of the next tiled GEMM launches */
+void p2v_debug_set_gemm_stamps(void* dev) { g_gemm_stamps = (unsigned long long*)dev; }
 
 int p2v_gelu_err_sweep(unsigned first_bits, unsigned count, float* max_err, void* stream) {
   if (!max_err) return fail(P2V_E_ARG, "p2v_gelu_err_sweep: null argument");

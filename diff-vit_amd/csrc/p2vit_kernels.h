@@ -19,6 +19,8 @@ struct GemmArgs {
   int ldo;
   int8_t* out_codes;
   int tiles_n;          // filled by the launcher
+  int stagger;          // first-round phase stagger in units of 64*127 cycles (0 = off)
+  unsigned long long* stamps;   // debug: per-block s_memtime stamps (5 per block) or null
   int dbg;              // ablation switches (P2V_GEMM_DBG): 1 skip k-loop, 2 skip epilogue arithmetic, 4 skip stores
 };
 

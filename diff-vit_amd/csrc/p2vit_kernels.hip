@@ -425,12 +425,17 @@ __device__ __forceinline__ void gemm_compute_tile_w4(const int8_t* cx, const int
 // Global->LDS staging goes through a 3-deep ring of NAMED registers (an indexed array
 // of prefetch registers is placed in scratch by hipcc: measured, 80 B private segment and a scratch round trip
 // per k-tile): tile t+3 is requested while tile t is computed, one barrier per k-tile.
+#define P2V_STAMP(slot)                                                                         \
+  do {                                                                                          \
+    if (g.stamps && threadIdx.x == 0) g.stamps[(long long)blockIdx.x * 6 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
 template <int EPI>
 __global__ __launch_bounds__(256, EPI == P2V_EPI_RESID ? 2 : 3) void k_gemm_i8_w4(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) int8_t lds[2 * (GBM + GBN) * GBK + sizeof(EpiLds)];
   int8_t* sX = lds;                    // [2][GBM][GBK] activation rows
   int8_t* sW = lds + 2 * GBM * GBK;    // [2][GBN][GBK] weight rows
   EpiLds* sE = reinterpret_cast<EpiLds*>(lds + 2 * (GBM + GBN) * GBK);
+  P2V_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -441,6 +446,13 @@ __global__ __launch_bounds__(256, EPI == P2V_EPI_RESID ? 2 : 3) void k_gemm_i8_w
   const int tn = t % g.tiles_n, tm = t / g.tiles_n;
   const int m0 = tm * GBM, n0 = tn * GBN;
 
+  // Co-resident workgroups start together and would stay in lock-step (loads, MFMAs and epilogues of all of them
+  // coincide: measured strictly additive phases).  The k-th workgroup placed on a CU in the FIRST round sleeps k thirds
+  // of a tile period, so that later rounds run one block's epilogue under another block's loads/MFMAs.
+  if (g.stagger > 0 && blockIdx.x < 768) {
+    const int phase = (int)(blockIdx.x >> 8);
+    for (int i = 0; i < phase * g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   const int lrow = tid >> 2, lchunk = tid & 3;
   int mr0 = m0 + lrow, mr1 = m0 + lrow + 64;
   mr0 = mr0 < g.M ? mr0 : g.M - 1;
@@ -496,6 +508,7 @@ __global__ __launch_bounds__(256, EPI == P2V_EPI_RESID ? 2 : 3) void k_gemm_i8_w
         if (m < g.M && n < g.N) resv[ni][mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
       }
   }
+  P2V_STAMP(1);
   for (int kt = 0; kt < ((g.dbg & 1) ? 0 : nk); kt += 3) {
     G_STEP(a, kt);
     if (kt + 1 < nk) G_STEP(b, kt + 1);
@@ -503,12 +516,16 @@ __global__ __launch_bounds__(256, EPI == P2V_EPI_RESID ? 2 : 3) void k_gemm_i8_w
   }
 #undef G_LOAD
 #undef G_STEP
+  __syncthreads();
+  P2V_STAMP(2);
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
       gemm_epilogue_tile<EPI>(acc[ni][mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, sE,
                               EPI == P2V_EPI_RESID ? resv[ni][mi] : make_uint4(0, 0, 0, 0));
+  P2V_STAMP(3);
+  if (g.stamps && threadIdx.x == 0) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g.stamps[(long long)blockIdx.x * 6 + 4] = xcc; unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g.stamps[(long long)blockIdx.x * 6 + 5] = hw; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1065,6 +1082,8 @@ __global__ __launch_bounds__(256) void k_gelu_err_sweep(unsigned first_bits, uns
 // host launchers (called from the C ABI in p2vit_capi.cpp)
 // ---------------------------------------------------------------------------------------------------
 int g_gemm_dbg = 0;
+unsigned long long* g_gemm_stamps = nullptr;
+int g_gemm_stagger = 0;  // P2V_GEMM_STAGGER=n
 int g_gemm_waves = 4;     // P2V_GEMM_WAVES=8: 8-wave (64x32 wave tile, <=128 VGPR) shape of the tiled kernel
 int g_use_resident = 0;   // P2V_GEMM_RESIDENT=0: tiled kernel everywhere (A/B runs)
 int g_use_panel = 0;   // P2V_GEMM_PANEL=1 selects the A-stationary panel kernel for K<=384 (A/B runs; measured slower: 1 block/CU)
@@ -1146,6 +1165,8 @@ static int launch_resident(const GemmArgs& g, hipStream_t st) {
 int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   GemmArgs g = g0;
   g.dbg = g_gemm_dbg;
+  g.stagger = g_gemm_stagger;
+  g.stamps = g_gemm_stamps;
   g.tiles_n = (g.N + GBN - 1) / GBN;
   const int tiles_m = (g.M + GBM - 1) / GBM;
   // resident kernel: K == 384, enough tiles to give every CU a few (else the tiled kernel's finer grain wins)

@@ -339,3 +339,25 @@ def test_harness_main_synthetic(dva, capsys):
     out = capsys.readouterr().out
     assert ' * Prec@1' in out and 'images/sec' in out and 'Calibrating with Gaussian noise' in out
     assert 0.0 <= top1 <= 100.0
+
+
+# --------------------------------------------------------------------------------------------------
+# other BASELINE configurations as parity cases: DeiT-T (cfg 1 shape), ViT-B int8 (cfg 3), DeiT-B W4 (cfg 5)
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name,bits', [('deit_tiny', 8), ('deit_tiny', 4), ('vit_base', 8), ('deit_base', 4)])
+def test_other_configs_engine_vs_oracle(dva, oracle, name, bits):
+    arch = dva.synth.ARCHS[name]
+    sd = dva.synth.vit_state_dict(arch, 21)
+    m = dva.harness.str2model(name)(cfg=dva.Config())
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda().eval()
+    dva.harness.calibrate_model(m, dva.synth.images(21, 2, 224).cuda())
+    x = dva.synth.images(21, 3, 224, offset=500)
+    cfgs = [[bits] * 50, [bits if i % 3 else 12 - bits for i in range(50)]]
+    orc = oracle.OracleViT(arch, sd)
+    orc.calib = m.export_calib()
+    for bc in cfgs:
+        out, flops, gd = m(x.cuda(), bc, False)
+        ref = orc.quant_forward(x, bc)
+        assert torch.equal(out.cpu(), ref), (name, bc[:6], int((out.cpu() != ref).sum()))
+        assert flops == orc.flops()
