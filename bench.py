@@ -53,6 +53,8 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH, help='images per GPU (BASELINE config 2: 256)')
     ap.add_argument('--bits', type=int, default=8, choices=(4, 8))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--model', default=MODEL, choices=('deit_tiny', 'deit_small', 'deit_base', 'vit_base'))
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for a rehearsal on one GPU)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -63,19 +65,20 @@ def main():
             sys.exit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ...' % (args.gpus, args.gpus))
     import diff_vit_amd as dva
     from diff_vit_amd import calib_io
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group(args.backend, **({'device_id': dev} if args.backend == 'nccl' else {}))
 
-    arch = dva.synth.ARCHS[MODEL]
+    arch = dva.synth.ARCHS[args.model]
     sd = dva.synth.vit_state_dict(arch, SEED)
     # the reference's flow through the drop-in surface: build, load, calibrate (float pass + observers, on the GPU),
     # model_quant(); the first quantized forward freezes the integer plan.  Calibration batch = the one the REAL
     # reference was calibrated on for tests/golden/deit_small.npz, so the resulting scales can be compared.
-    model = dva.deit_small_patch16_224(cfg=dva.Config(True, True, 'minmax'))
+    model = dva.harness.str2model(args.model)(cfg=dva.Config(True, True, 'minmax'))
     model.load_state_dict(sd, strict=False)
     model = model.to(dev).eval()
     t_cal = time.perf_counter()
@@ -83,12 +86,12 @@ def main():
     torch.cuda.synchronize()
     t_cal = time.perf_counter() - t_cal
     calib = model.export_calib()
-    ref_calib = calib_io.flatten(calib_io.load_npz(os.path.join(ROOT, 'tests', 'golden', 'deit_small.npz')))
     mine = calib_io.flatten(calib)
+    ref_calib = calib_io.flatten(calib_io.load_npz(os.path.join(ROOT, 'tests', 'golden', 'deit_small.npz'))) if args.model == MODEL else mine
     pot = [k for k in ref_calib if bool((torch.frexp(ref_calib[k].reshape(-1))[0] == 0.5).all())]
     pot_same = all(torch.equal(mine[k].reshape(-1), ref_calib[k].reshape(-1)) for k in pot)
     ptf_rel = max(float(((mine[k].reshape(-1) - ref_calib[k].reshape(-1)).abs() / ref_calib[k].reshape(-1)).max())
-                  for k in ref_calib if k not in pot)
+                  for k in ref_calib if k not in pot) if len(pot) < len(ref_calib) else 0.0
     plan = model.freeze(dev)
     B = args.batch
     # 32 distinct synthetic images per rank, tiled to the batch (content does not change the work)
@@ -173,11 +176,11 @@ def main():
 
     if rank == 0:
         print(json.dumps({
-            'metric': 'images/sec DeiT-S int8 224^2 b=256 (quantized forward)', 'value': round(value, 1), 'unit': 'images/sec',
+            'metric': 'images/sec DeiT-S int8 224^2 b=256 (quantized forward)' if args.model == MODEL else 'images/sec %s (quantized forward)' % args.model, 'value': round(value, 1), 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(el / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int%d' % args.bits if args.bits == 8 else 'int4w/int8a',
             'data': 'synthetic',
-            'config': {'workload': 'deit_small PoT-PTQ forward, bit_config=[%d]*50, 224x224, batch %d per GPU' % (args.bits, B),
+            'config': {'workload': args.model + ' PoT-PTQ forward, bit_config=[%d]*50, 224x224, batch %d per GPU' % (args.bits, B),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world,
                        'collective': 'all_gather(logits)' if world > 1 else 'none'},
             'roofline': roof,
