@@ -145,7 +145,7 @@ def main():
     roof['launches_per_step'] = len(prof[dom]) // 5
     roof['traffic'] = None
     pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and args.model == MODEL and B == BATCH:
         try:
             roof['traffic'] = json.load(open(pmc)).get(dom)
         except Exception:

@@ -239,6 +239,36 @@ class FrozenPlan:
                                     ws.numel(), stop_after, E.stream_ptr()))
         return out
 
+    def forward_streams(self, images, bit_config, out, n_streams=2):
+        """Same result as ``forward``; the batch is cut into ``n_streams`` contiguous slices that run on their own HIP
+        streams with their own workspaces.  Images are independent, so this is only a scheduling choice: kernels of one
+        slice (e.g. a VALU-bound GELU epilogue) overlap latency- or MFMA-bound phases of another slice's kernels."""
+        images = images.contiguous().float()
+        B = images.shape[0]
+        if n_streams <= 1 or B < 2 * n_streams:
+            return self.forward(images, bit_config, out=out)
+        cfg = (C.c_int8 * len(bit_config))(*[int(b) for b in bit_config])
+        if getattr(self, '_streams', None) is None or len(self._streams) != n_streams:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+            self._ws_multi = [None] * n_streams
+        cur = torch.cuda.current_stream(self.device)
+        step = (B + n_streams - 1) // n_streams
+        L = E.lib()
+        for i, st in enumerate(self._streams):
+            lo, hi = i * step, min(B, (i + 1) * step)
+            if lo >= hi:
+                break
+            n = L.p2v_workspace_bytes(self._handle, hi - lo)
+            if self._ws_multi[i] is None or self._ws_multi[i].numel() < n:
+                self._ws_multi[i] = torch.empty(n, dtype=torch.uint8, device=self.device)
+            st.wait_stream(cur)
+            xi, oi = images[lo:hi], out[lo:hi]
+            E.check(L.p2v_forward(self._handle, E.ptr(xi), hi - lo, cfg, len(bit_config), E.ptr(oi), E.ptr(self._ws_multi[i]),
+                                  self._ws_multi[i].numel(), -1, C.c_void_p(st.cuda_stream)))
+        for st in self._streams:
+            cur.wait_stream(st)
+        return out
+
     def profile(self, images, bit_config):
         """per-launch times (ms, HIP events on the launch stream) of one forward: [(kind_name, ms), ...]."""
         images = images.contiguous().float()
