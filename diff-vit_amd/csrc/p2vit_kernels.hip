@@ -56,7 +56,7 @@ __device__ __forceinline__ void row16_to_halves(uint4 e, unsigned& g0, unsigned&
 // GELU_EPS/s from a rounding boundary the code is already decided.  Otherwise (about 1e-4 of the
 // elements) the lane takes the fp64 path.  tests/test_gelu_gpu.py sweeps the fp32 line to check the bound.
 // ---------------------------------------------------------------------------------------------------
-#define GELU_EPS 4.0e-6f
+#define GELU_EPS 1.2e-6f   // measured max |gelu_fast - RN32(gelu)| over all fp32 in +-[2^-20,32): 4.8e-7 (tools/gelu_stats.py)
 // approximation only (its error is bounded by the exhaustive sweep in tests): fused multiply-adds are fine here
 __device__ __forceinline__ float gelu_fast(float y) {
   const float z = fabsf(y) * 0.70710678f;
@@ -660,9 +660,70 @@ __global__ __launch_bounds__(512, 2) void k_gemm_panel(GemmArgs g, int tpg) {
 //   that ride under the four epilogue sub-tiles of tile t (the epilogue is the long, VALU-bound phase).
 //   8 waves (2 per SIMD), wave tile 64x64, one workgroup per CU, grid = #CUs.
 // ---------------------------------------------------------------------------------------------------
-#define RBM 256
+// ---- epilogue of the resident kernel -----------------------------------------------------------------------------------
+// Same arithmetic as gemm_epilogue_tile.  Two differences that only matter while an LDS-DMA is in flight:
+//  * the per-channel constants are read from LDS with inline-asm ds_read_b128: hipcc inserts s_waitcnt vmcnt(0) in front
+//    of any LDS access it can see while a global_load_lds is pending (it cannot prove the constants do not alias the DMA
+//    destination), which would serialise the prefetch behind the epilogue (seen in the ISA);
+//  * the packed result is RETURNED, not stored: the caller stores it after the barrier that retires the DMA, so that the
+//    barrier's vmcnt(0) never waits for this tile's own output stores (vmcnt counts stores on CDNA).
+struct EpiRegs { float4 cs, bs, sm, sr, sn, rm, rn; };
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void k_gemm_resident(GemmArgs g, int tiles_total, int tiles_per_block) {
+__device__ __forceinline__ EpiRegs lds_epi_consts(const EpiLds* e, int c) {
+  EpiRegs r;
+  const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)(e->colscale + c);
+  if (EPI == P2V_EPI_RESID) {
+    asm volatile(
+        "ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:512\n\tds_read_b128 %2, %7 offset:1024\n\tds_read_b128 %3, %7 offset:1536\n\t"
+        "ds_read_b128 %4, %7 offset:2048\n\tds_read_b128 %5, %7 offset:2560\n\tds_read_b128 %6, %7 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(r.cs), "=&v"(r.bs), "=&v"(r.sm), "=&v"(r.sr), "=&v"(r.sn), "=&v"(r.rm), "=&v"(r.rn)
+        : "v"(a));
+  } else {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r.cs), "=&v"(r.bs) : "v"(a));
+  }
+  return r;
+}
+
+template <int EPI>
+__device__ __forceinline__ uint4 gemm_epilogue_tile_res(const v16i& acc, int nl, int h, const GemmArgs& g, const EpiLds* e, uint4 resv) {
+  unsigned d[4], res[4];
+  if (EPI == P2V_EPI_RESID) row16_to_halves(resv, res[0], res[1], res[2], res[3]);
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const EpiRegs k = lds_epi_consts<EPI>(e, nl + 8 * gq + 4 * h);
+    float y[4];
+    y[0] = __builtin_fmaf((float)acc[4 * gq + 0], k.cs.x, k.bs.x);   // exact product: one rounding (see gemm_epilogue_tile)
+    y[1] = __builtin_fmaf((float)acc[4 * gq + 1], k.cs.y, k.bs.y);
+    y[2] = __builtin_fmaf((float)acc[4 * gq + 2], k.cs.z, k.bs.z);
+    y[3] = __builtin_fmaf((float)acc[4 * gq + 3], k.cs.w, k.bs.w);
+    int q[4];
+    if (EPI == P2V_EPI_REQUANT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = sat8(y[i] * g.ep.inv_s_out);
+    } else if (EPI == P2V_EPI_GELU) {
+      gelu_q8x4(y, g.ep.inv_s_out, q);
+    } else {
+      const float smv[4] = {k.sm.x, k.sm.y, k.sm.z, k.sm.w}, srv[4] = {k.sr.x, k.sr.y, k.sr.z, k.sr.w};
+      const float snv[4] = {k.sn.x, k.sn.y, k.sn.z, k.sn.w}, rmv[4] = {k.rm.x, k.rm.y, k.rm.z, k.rm.w}, rnv[4] = {k.rn.x, k.rn.y, k.rn.z, k.rn.w};
+      float q3[4], xs[4], qo[4];
+      div_q8fx4(y, smv, rmv, q3);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xs[i] = (float)sx8(res[gq], i) * srv[i] + q3[i] * smv[i];
+      div_q8fx4(xs, snv, rnv, qo);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = (int)qo[i];
+    }
+    d[gq] = pack4(q[0], q[1], q[2], q[3]);
+    if (EPI == P2V_EPI_RESID) __builtin_amdgcn_sched_barrier(0);
+  }
+  return halves_to_row16(d[0], d[1], d[2], d[3]);
+}
+
+#define RBM 256
+// 16 waves (4 per SIMD: the fp32 epilogue chains issue at ~2.1 cycles/instruction only with >= 4 waves per SIMD, measured),
+// 4 (m) x 4 (n) waves of 64 x 32 outputs, <= 128 VGPRs.
+template <int EPI>
+__global__ __launch_bounds__(1024, 4) void k_gemm_resident(GemmArgs g, int tiles_total, int tiles_per_block) {
   constexpr int KP = 384, NKT = KP / GBK, CPR = KP / 16;      // k-tiles, 16-byte chunks per row
   constexpr int ATILE = RBM * GBK, WTILE = GBN * GBK;
   extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
@@ -671,113 +732,100 @@ __global__ __launch_bounds__(512, 2) void k_gemm_resident(GemmArgs g, int tiles_
   EpiLds* sE = reinterpret_cast<EpiLds*>(sW + NKT * WTILE);     // [2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 2, wn = wave & 3;
   const int t_begin = blockIdx.x * tiles_per_block;
   int t_end = t_begin + tiles_per_block;
   t_end = t_end < tiles_total ? t_end : tiles_total;
   if (t_begin >= t_end) return;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int lr = lane >> 2, pc = lane & 3;
 
-  // element (row, chunk) of load slot c for this thread: e = tid + 512*c
-#define R_A_ADDR(c, mp_)                                                                      \
-  (g.A + (long long)((mp_) * RBM + (tid + 512 * (c)) / CPR < g.M ? (mp_) * RBM + (tid + 512 * (c)) / CPR : g.M - 1) * g.lda + \
-   ((tid + 512 * (c)) % CPR) * 16)
-#define R_W_ADDR(c, tn_) (g.W + (long long)((tn_) * GBN + (tid + 512 * (c)) / CPR) * g.K + ((tid + 512 * (c)) % CPR) * 16)
-#define R_A_LDS(c) (sA + (((tid + 512 * (c)) % CPR) >> 2) * ATILE + lds_off64((tid + 512 * (c)) / CPR, ((tid + 512 * (c)) % CPR) & 3))
-#define R_W_LDS(c) (sW + (((tid + 512 * (c)) % CPR) >> 2) * WTILE + lds_off64((tid + 512 * (c)) / CPR, ((tid + 512 * (c)) % CPR) & 3))
-  {
-    const int mp = t_begin / g.tiles_n, tn = t_begin % g.tiles_n;
+  // LDS-DMA of a whole-K operand: a wave-instruction writes 64 x 16 B linearly = 16 rows of a [rows][64] sub-tile, so the
+  // XOR swizzle goes on the per-lane SOURCE address: slot (row, pc) receives logical chunk pc ^ ((row>>2)&3).
+  auto dma_A = [&](int mp_) {
 #pragma unroll
-    for (int c = 0; c < 12; ++c) *reinterpret_cast<uint4*>(R_A_LDS(c)) = *reinterpret_cast<const uint4*>(R_A_ADDR(c, mp));
+    for (int i = 0; i < 6; ++i) {
+      const int jj = wv + 16 * i, rb = jj & 15, kt = jj >> 4;
+      const int row = rb * 16 + lr;
+      int mr = mp_ * RBM + row;
+      mr = mr < g.M ? mr : g.M - 1;
+      const int8_t* src = g.A + (long long)mr * g.lda + kt * GBK + ((pc ^ ((row >> 2) & 3)) << 4);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sA + kt * ATILE + rb * 16 * GBK), 16, 0, 0);
+    }
+  };
+  auto dma_W = [&](int tn_) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) *reinterpret_cast<uint4*>(R_W_LDS(c)) = *reinterpret_cast<const uint4*>(R_W_ADDR(c, tn));
-    gemm_stage_epilogue<EPI>(&sE[0], tn * GBN, tid, g);
-  }
-  __syncthreads();
+    for (int i = 0; i < 3; ++i) {
+      const int jj = wv + 16 * i, rb = jj & 7, kt = jj >> 3;
+      const int row = rb * 16 + lr;
+      const int8_t* src = g.W + (long long)(tn_ * GBN + row) * g.K + kt * GBK + ((pc ^ ((row >> 2) & 3)) << 4);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sW + kt * WTILE + rb * 16 * GBK), 16, 0, 0);
+    }
+  };
+  dma_A(t_begin / g.tiles_n);
+  dma_W(t_begin % g.tiles_n);
+  gemm_stage_epilogue<EPI>(&sE[0], (t_begin % g.tiles_n) * GBN, tid, g);
+  __syncthreads();          // carries the vmcnt(0) that retires the LDS-DMA
 
   for (int t = t_begin, it = 0; t < t_end; ++t, ++it) {
     const int mp = t / g.tiles_n, tn = t % g.tiles_n;
     const int m0 = mp * RBM, n0 = tn * GBN;
     const bool more = t + 1 < t_end;
     const int mp2 = more ? (t + 1) / g.tiles_n : mp, tn2 = more ? (t + 1) % g.tiles_n : tn;
-    const bool newA = more && mp2 != mp;
-    uint4 resv[2][2];
+    uint4 resv[2];
     if (EPI == P2V_EPI_RESID) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 64 + ni * 32 + 16 * h;
-          resv[ni][mi] = make_uint4(0, 0, 0, 0);
-          if (m < g.M && n < g.N) resv[ni][mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
-        }
+      for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 32 + 16 * h;
+        resv[mi] = make_uint4(0, 0, 0, 0);
+        if (m < g.M && n < g.N) resv[mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
+      }
     }
-    v16i acc[2][2];
+    if (g.stamps && tid == 0 && it < 8) g.stamps[((long long)blockIdx.x * 8 + it) * 4 + 0] = __builtin_readcyclecounter();
+    v16i acc[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+      for (int r = 0; r < 16; ++r) acc[a][r] = 0;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        v4i fw[2], fx[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          fw[i] = *reinterpret_cast<const v4i*>(sW + kt * WTILE + lds_off64(wn * 64 + i * 32 + l31, 2 * ks + h));
-          fx[i] = *reinterpret_cast<const v4i*>(sA + kt * ATILE + lds_off64(wm * 64 + i * 32 + l31, 2 * ks + h));
-        }
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[ni], fx[mi], acc[ni][mi], 0, 0, 0);
+        const v4i fw = *reinterpret_cast<const v4i*>(sW + kt * WTILE + lds_off64(wn * 32 + l31, 2 * ks + h));
+        const v4i f0 = *reinterpret_cast<const v4i*>(sA + kt * ATILE + lds_off64(wm * 64 + l31, 2 * ks + h));
+        const v4i f1 = *reinterpret_cast<const v4i*>(sA + kt * ATILE + lds_off64(wm * 64 + 32 + l31, 2 * ks + h));
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw, f0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw, f1, acc[1], 0, 0, 0);
       }
     }
-    __syncthreads();          // every wave has read its fragments: the operand buffers may be overwritten
-
-    // The operands of tile t+1 go global -> LDS by LDS-DMA (no VGPRs): every request is issued here, flies under
-    // the whole epilogue of tile t, and is retired by the vmcnt(0) that __syncthreads() carries.  An LDS-DMA
-    // wave-instruction writes 64 x 16 B linearly (16 rows of a [rows][64] sub-tile), so the XOR swizzle is
-    // applied to the per-lane SOURCE address: slot (row, pc) receives logical chunk pc ^ ((row>>2)&3).
-    if (more) {
-      const int wv = __builtin_amdgcn_readfirstlane(wave);
-      const int lr = lane >> 2, pc = lane & 3;
-      if (newA) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-          const int jj = wv + 8 * i, rb = jj & 15, kt = jj >> 4;
-          const int row = rb * 16 + lr;
-          int mr = mp2 * RBM + row;
-          mr = mr < g.M ? mr : g.M - 1;
-          const int8_t* src = g.A + (long long)mr * g.lda + kt * GBK + ((pc ^ ((row >> 2) & 3)) << 4);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(sA + kt * ATILE + rb * 16 * GBK), 16, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int jj = wv + 8 * i, rb = jj & 7, kt = jj >> 3;
-        const int row = rb * 16 + lr;
-        const int8_t* src = g.W + (long long)(tn2 * GBN + row) * g.K + kt * GBK + ((pc ^ ((row >> 2) & 3)) << 4);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(sW + kt * WTILE + rb * 16 * GBK), 16, 0, 0);
-      }
+    // every wave has read its fragments -> the operand buffers may be overwritten.  Raw barrier: only the LDS reads have
+    // to be complete (lgkmcnt); a __syncthreads() here would also wait for the previous tile's output stores.
+    if (g.stamps && tid == 0 && it < 8) g.stamps[((long long)blockIdx.x * 8 + it) * 4 + 1] = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (more) {     // operands of tile t+1 fly under the whole epilogue of tile t
+      if (mp2 != mp) dma_A(mp2);
+      dma_W(tn2);
     }
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        gemm_epilogue_tile<EPI>(acc[ni][mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, &sE[it & 1],
-                                EPI == P2V_EPI_RESID ? resv[ni][mi] : make_uint4(0, 0, 0, 0));
+    uint4 o0 = gemm_epilogue_tile_res<EPI>(acc[0], wn * 32, h, g, &sE[it & 1], EPI == P2V_EPI_RESID ? resv[0] : make_uint4(0, 0, 0, 0));
+    uint4 o1 = gemm_epilogue_tile_res<EPI>(acc[1], wn * 32, h, g, &sE[it & 1], EPI == P2V_EPI_RESID ? resv[1] : make_uint4(0, 0, 0, 0));
+    if (g.stamps && tid == 0 && it < 8) g.stamps[((long long)blockIdx.x * 8 + it) * 4 + 2] = __builtin_readcyclecounter();
+    if (g.stamps && lane == 0 && it < 8 && blockIdx.x < 16) g.stamps[8192 + ((long long)blockIdx.x * 8 + it) * 32 + wave] = __builtin_readcyclecounter();
     if (more) gemm_stage_epilogue<EPI>(&sE[(it + 1) & 1], tn2 * GBN, tid, g);
-    __syncthreads();
+    // DMA landed + next constants written; the outstanding VMEM ops at this point are the DMA (issued an epilogue ago) and
+    // the previous tile's stores (issued a whole tile ago)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (g.stamps && lane == 0 && it < 8 && blockIdx.x < 16) g.stamps[8192 + ((long long)blockIdx.x * 8 + it) * 32 + 16 + wave] = __builtin_readcyclecounter();
+    asm volatile("s_barrier" ::: "memory");
+    if (g.stamps && tid == 0 && it < 8) g.stamps[((long long)blockIdx.x * 8 + it) * 4 + 3] = __builtin_readcyclecounter();
+    {
+      const int n = n0 + wn * 32 + 16 * h;
+      const int ma = m0 + wm * 64 + l31, mb = ma + 32;
+      if (ma < g.M && n < g.N) *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)ma * g.ldo + n) = o0;
+      if (mb < g.M && n < g.N) *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)mb * g.ldo + n) = o1;
+    }
   }
-#undef R_A_ADDR
-#undef R_W_ADDR
-#undef R_A_LDS
-#undef R_W_LDS
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1157,7 +1205,7 @@ static int launch_resident(const GemmArgs& g, hipStream_t st) {
   int blocks = n_cu < tiles_total ? n_cu : tiles_total;
   const int tpb = (tiles_total + blocks - 1) / blocks;
   blocks = (tiles_total + tpb - 1) / tpb;
-  hipLaunchKernelGGL((k_gemm_resident<EPI>), dim3(blocks), dim3(512), smem, st, g, tiles_total, tpb);
+  hipLaunchKernelGGL((k_gemm_resident<EPI>), dim3(blocks), dim3(1024), smem, st, g, tiles_total, tpb);
   CHECK_LAUNCH();
   return 0;
 }

@@ -27,6 +27,25 @@ __global__ void k(float* out, float a, float b, int n) {
       x4 = (float)((int)x4 + 1); x5 = (float)((int)x5 + 1); x6 = (float)((int)x6 + 1); x7 = (float)((int)x7 + 1);
     } else if (OP == 5) {  // packed mul
       p0 = p0 * pa; p1 = p1 * pa; p2 = p2 * pa; p3 = p3 * pa;
+    } else if (OP == 6) {  // fma with a 32-bit literal (64-bit encoding)
+      asm volatile("v_fmaak_f32 %0, %0, %8, 0x3e827906\n\tv_fmaak_f32 %1, %1, %8, 0x3e827907\n\tv_fmaak_f32 %2, %2, %8, 0x3e827908\n\tv_fmaak_f32 %3, %3, %8, 0x3e827909\n\t"
+                   "v_fmaak_f32 %4, %4, %8, 0x3e82790a\n\tv_fmaak_f32 %5, %5, %8, 0x3e82790b\n\tv_fmaak_f32 %6, %6, %8, 0x3e82790c\n\tv_fmaak_f32 %7, %7, %8, 0x3e82790d"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+    } else if (OP == 7) {  // fma with three VGPR sources
+      asm volatile("v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\t"
+                   "v_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9"
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+    } else if (OP == 8) {  // compare -> VCC -> cndmask chain
+      x0 = x0 > a ? x0 * b : x0; x1 = x1 > a ? x1 * b : x1; x2 = x2 > a ? x2 * b : x2; x3 = x3 > a ? x3 * b : x3;
+      x4 = x4 > a ? x4 * b : x4; x5 = x5 > a ? x5 * b : x5; x6 = x6 > a ? x6 * b : x6; x7 = x7 > a ? x7 * b : x7;
+    } else if (OP == 9) {  // dependent chain of 4 plain ops per value (ILP 8)
+      x0 = rintf(fmaxf(x0 * a, b) - b); x1 = rintf(fmaxf(x1 * a, b) - b); x2 = rintf(fmaxf(x2 * a, b) - b); x3 = rintf(fmaxf(x3 * a, b) - b);
+      x4 = rintf(fmaxf(x4 * a, b) - b); x5 = rintf(fmaxf(x5 * a, b) - b); x6 = rintf(fmaxf(x6 * a, b) - b); x7 = rintf(fmaxf(x7 * a, b) - b);
+    } else if (OP == 10) {  // same chain with ILP 2 only
+      x0 = rintf(fmaxf(x0 * a, b) - b); x1 = rintf(fmaxf(x1 * a, b) - b);
+      x0 = rintf(fmaxf(x0 * a, b) - b); x1 = rintf(fmaxf(x1 * a, b) - b);
+      x0 = rintf(fmaxf(x0 * a, b) - b); x1 = rintf(fmaxf(x1 * a, b) - b);
+      x0 = rintf(fmaxf(x0 * a, b) - b); x1 = rintf(fmaxf(x1 * a, b) - b);
     }
   }
   long long t1 = clock64();
@@ -38,15 +57,16 @@ template <int OP> void run(const char* name, int instr_per_iter, float* d) {
   for (int wps = 1; wps <= 4; wps *= 2) {   // waves per SIMD: block of 256*wps threads, one block per CU
     hipLaunchKernelGGL(k<OP>, dim3(256), dim3(256 * wps), 0, 0, d, 1.0001f, 0.5f, ITER);
     hipDeviceSynchronize();
-    float h[8]; hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    float h[16]; hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
     printf("%-18s waves/SIMD=%d  clock64 ticks/iter=%.1f  -> %.2f ticks per wave-instruction (per wave); per SIMD %.2f\n", name, wps, h[1 + OP],
            h[1 + OP] / instr_per_iter, h[1 + OP] / instr_per_iter / wps);
   }
 }
 int main() {
-  float* d; hipMalloc(&d, 64); hipMemset(d, 0, 64);
+  float* d; hipMalloc(&d, 128); hipMemset(d, 0, 128);
   run<0>("v_fma_f32 x8", 8, d); run<1>("v_pk_fma_f32 x4", 4, d); run<5>("v_pk_mul_f32 x4", 4, d);
   run<2>("mul+rndne x8", 16, d); run<3>("v_exp_f32 x8", 8, d); run<4>("cvt,add,cvt x8", 24, d);
+  run<6>("v_fmaak literal x8", 8, d); run<7>("v_fma 3 vgpr x8", 8, d); run<8>("cmp+cndmask+mul x8", 24, d); run<9>("chain4 ILP8", 32, d); run<10>("chain4 ILP2", 32, d);
   // wall-clock rate: fma
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int wps = 1; wps <= 4; wps *= 2) {
