@@ -52,6 +52,7 @@ extern "C" {
 
 extern int g_use_panel;
 extern int g_gemm_waves;
+extern int g_attn_waves;
 extern unsigned long long* g_gemm_stamps;
 extern int g_gemm_stagger;
 extern int g_use_resident;
@@ -68,6 +69,8 @@ static void read_env_once() {
   if (e) g_gemm_waves = atoi(e);
   e = getenv("P2V_GEMM_STAGGER");
   if (e) g_gemm_stagger = atoi(e);
+  e = getenv("P2V_ATTN_WAVES");
+  if (e && atoi(e) >= 4 && atoi(e) <= 8) g_attn_waves = atoi(e);
   e = getenv("P2V_GEMM_DBG");
   if (e) g_gemm_dbg = atoi(e);
 }

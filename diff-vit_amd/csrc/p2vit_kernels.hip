@@ -972,7 +972,7 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
     }
   }
   // stage K rows (swizzled so that a 16-row x 16-byte-chunk fragment read is conflict free) and V^T (bf16)
-  for (int i = tid; i < KROWS * CH; i += 512) {
+  for (int i = tid; i < KROWS * CH; i += (int)blockDim.x) {
     const int row = i / CH, c = i % CH;
     uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
     if (row < N) {
@@ -994,7 +994,8 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
   // the single rounding of the *scale product (vit_fquant.py:316-317)
   const float m1 = a.at.qk_scale, m2 = a.at.s_qkv_sq * a.at.inv_s_attn;
   const int nqb = (N + 15) >> 4;
-  for (int qb = wave; qb < nqb; qb += 8) {
+  const int nwaves = (int)(blockDim.x >> 6);
+  for (int qb = wave; qb < nqb; qb += nwaves) {
     const int qrow = qb * 16 + l15;
     const int qr = qrow < N ? qrow : N - 1;
     v4i fq = {0, 0, 0, 0};
@@ -1008,10 +1009,15 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
       if (g >= CH) fk = (v4i){0, 0, 0, 0};
       s[kb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq, (v4i){0, 0, 0, 0}, 0, 0, 0);
     }
+    const bool tail_empty = (NKB - 1) * 16 >= N;     // last 16-key block holds only padding (e.g. N = 197: keys 208..223)
     // scores -> int8 codes of qact_attn1 ; row max.  Padded keys (only in the last 32-key pair) get -1000.
     int mx = -1000;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
+      if (kb == NKB - 1 && tail_empty) {             // wave-uniform: no arithmetic for a block of padding
+        s[kb] = (v4i){-1000, -1000, -1000, -1000};
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int c8 = sat8(((float)s[kb][r] * m1) * m2);
@@ -1029,6 +1035,10 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
     long long S = 0;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
+      if (kb == NKB - 1 && tail_empty) {
+        s[kb] = (v4i){256, 256, 256, 256};
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int d = mx - s[kb][r];
@@ -1056,6 +1066,10 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
           const int j = 2 * e2 + e;                              // element of the 8-wide B fragment
           const int kb = 2 * p + (j >> 2), r = j & 3;
           const int d = s[kb][r];
+          if (kb == NKB - 1 && tail_empty) {                     // (compile-time kb, wave-uniform flag)
+            hw2[e] = 0u;
+            continue;
+          }
           const float ratio = rintf(Sf / lutF[d]);              // round(sum / exp_int), layers.py:370
           int k = (int)((__float_as_uint(ratio) + 0x00400000u) >> 23) - 127;   // log_round, layers.py:323-329
           k = k > 16 ? 16 : k;                                   // ratio >= 1, so k >= 0
@@ -1130,6 +1144,7 @@ __global__ __launch_bounds__(256) void k_gelu_err_sweep(unsigned first_bits, uns
 // host launchers (called from the C ABI in p2vit_capi.cpp)
 // ---------------------------------------------------------------------------------------------------
 int g_gemm_dbg = 0;
+int g_attn_waves = 8;     // P2V_ATTN_WAVES
 unsigned long long* g_gemm_stamps = nullptr;
 int g_gemm_stagger = 0;  // P2V_GEMM_STAGGER=n
 int g_gemm_waves = 4;     // P2V_GEMM_WAVES=8: 8-wave (64x32 wave tile, <=128 VGPR) shape of the tiled kernel
@@ -1281,9 +1296,9 @@ static int launch_attn_t(const AttnArgs& a, hipStream_t st) {
   constexpr int KROWS = NKB * 32;   // NKB here = 32-key pairs
   constexpr size_t smem = (size_t)KROWS * HD + (size_t)HD * (KROWS + 4) * 2 + 258 * 8 + 260 * 4;
   if (a.probs_k)
-    hipLaunchKernelGGL((k_lis_attention<HD, NKB, true>), dim3(a.B * a.H), dim3(512), smem, st, a);
+    hipLaunchKernelGGL((k_lis_attention<HD, NKB, true>), dim3(a.B * a.H), dim3(64 * g_attn_waves), smem, st, a);
   else
-    hipLaunchKernelGGL((k_lis_attention<HD, NKB, false>), dim3(a.B * a.H), dim3(512), smem, st, a);
+    hipLaunchKernelGGL((k_lis_attention<HD, NKB, false>), dim3(a.B * a.H), dim3(64 * g_attn_waves), smem, st, a);
   CHECK_LAUNCH();
   return 0;
 }
