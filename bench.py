@@ -89,10 +89,11 @@ def main():
     calib = model.export_calib()
     mine = calib_io.flatten(calib)
     ref_calib = calib_io.flatten(calib_io.load_npz(os.path.join(ROOT, 'tests', 'golden', 'deit_small.npz'))) if args.model == MODEL else mine
-    pot = [k for k in ref_calib if bool((torch.frexp(ref_calib[k].reshape(-1))[0] == 0.5).all())]
-    pot_same = all(torch.equal(mine[k].reshape(-1), ref_calib[k].reshape(-1)) for k in pot)
-    ptf_rel = max(float(((mine[k].reshape(-1) - ref_calib[k].reshape(-1)).abs() / ref_calib[k].reshape(-1)).max())
-                  for k in ref_calib if k not in pot) if len(pot) < len(ref_calib) else 0.0
+    # agreement with the REAL reference's calibration of the same weights/batch (float pass: expect ulp-level noise in the
+    # PTF base scales and, on near-ties of the per-channel MSE search, an occasional exponent one step away)
+    n_equal = sum(int(torch.equal(mine[k].reshape(-1), ref_calib[k].reshape(-1))) for k in ref_calib)
+    exp_flips = sum(int((torch.log2(mine[k].reshape(-1) / ref_calib[k].reshape(-1)).abs() > 0.5).sum()) for k in ref_calib)
+    n_elems = sum(ref_calib[k].numel() for k in ref_calib)
     plan = model.freeze(dev)
     B = args.batch
     # 32 distinct synthetic images per rank, tiled to the batch (content does not change the work)
@@ -190,8 +191,8 @@ def main():
             'model_mfma_frac': round(model_ops / (el / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
             'kernel_ms_per_step': breakdown,
             'cpu_baseline': cpu,
-            'calibration': {'seconds': round(t_cal, 2), 'device': 'gpu', 'pot_scales_equal_reference': bool(pot_same), 'n_pot': len(pot),
-                            'ptf_scale_max_rel_diff_vs_reference': ptf_rel},
+            'calibration': {'seconds': round(t_cal, 2), 'device': 'gpu', 'tensors': len(ref_calib), 'tensors_bit_equal_reference': n_equal,
+                            'scale_elements': n_elems, 'elements_off_by_a_power_of_two': exp_flips},
         }))
     if world > 1:
         dist.destroy_process_group()
