@@ -33,6 +33,17 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
   return (unsigned)(a & 255) | ((unsigned)(b & 255) << 8) | ((unsigned)(c & 255) << 16) | ((unsigned)d << 24);
 }
 __device__ __forceinline__ int sx8(unsigned w, int i) { return (int)(int8_t)(w >> (8 * i)); }
+// clamp(r, -128, 127) of four INTEGRAL floats (already rounded with rintf) as four int8 bytes.  v_cvt_pk_u8_f32 saturates to
+// [0,255] (measured on gfx950: 256, 1e9, +inf -> 255; -1, -1e9, -inf, NaN -> 0) and r + 128 is exact for |r| < 2^24 (beyond that
+// the value saturates anyway), so  clamp(r,-128,127) == (sat_u8(r + 128)) ^ 0x80  byte-wise: 2 instructions per value + 1 per dword.
+__device__ __forceinline__ unsigned pack4_sat(float r0, float r1, float r2, float r3) {
+  unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(r0 + 128.f, 0, 0u);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(r1 + 128.f, 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(r2 + 128.f, 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(r3 + 128.f, 3, w);
+  return w ^ 0x80808080u;
+}
+__device__ __forceinline__ float sat8f(float v) { return fminf(fmaxf(rintf(v), -128.f), 127.f); }
 
 // Exchange between the two 32-lane halves so that each lane ends with 16 CONTIGUOUS bytes of an MFMA
 // 32x32 accumulator column block.  In: d[g] = bytes [8g+4h, 8g+4h+4) (h = lane>>5).
@@ -93,7 +104,7 @@ __device__ __forceinline__ int gelu_q8(float y, float inv_s, bool force_slow, bo
 
 // Four at a time: the fast values are computed branch-free (instruction-level parallelism across the four
 // dependent chains), ONE wave-uniform branch covers the rare lanes that need the fp64 value.
-__device__ __forceinline__ void gelu_q8x4(const float (&y)[4], float inv_s, int (&q)[4]) {
+__device__ __forceinline__ void gelu_q8x4(const float (&y)[4], float inv_s, float (&q)[4]) {
   float r[4];
   bool slow[4], any = !(GELU_EPS * inv_s < 0.25f);
 #pragma unroll
@@ -109,7 +120,7 @@ __device__ __forceinline__ void gelu_q8x4(const float (&y)[4], float inv_s, int 
       if (slow[i] || !(GELU_EPS * inv_s < 0.25f)) r[i] = rintf(gelu_exact(y[i]) * inv_s);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) q[i] = (int)fminf(fmaxf(r[i], -128.f), 127.f);
+  for (int i = 0; i < 4; ++i) q[i] = r[i];          // integral, NOT clamped: the byte packing saturates
 }
 
 // clamp(rne(x / s), -128, 127) with IEEE-division semantics (the reference divides by the non-power-of-two
@@ -125,6 +136,7 @@ __device__ __forceinline__ float div_q8f(float x, float s, float rs) {
   }
   return fminf(fmaxf(r, -128.f), 127.f);
 }
+template <bool CLAMP>
 __device__ __forceinline__ void div_q8fx4(const float (&x)[4], const float (&s)[4], const float (&rs)[4], float (&out)[4]) {
   float r[4];
   bool slow[4], any = false;
@@ -141,7 +153,7 @@ __device__ __forceinline__ void div_q8fx4(const float (&x)[4], const float (&s)[
       if (slow[i]) r[i] = rintf(x[i] / s[i]);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) out[i] = fminf(fmaxf(r[i], -128.f), 127.f);
+  for (int i = 0; i < 4; ++i) out[i] = CLAMP ? fminf(fmaxf(r[i], -128.f), 127.f) : r[i];   // unclamped when the caller packs (saturating)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256) void k_quantize_patchify(const float* __restri
       int px = (int)(row % gw), py = (int)((row / gw) % gh), b = (int)(row / ((long long)gw * gh));
       const float* src = img + (((long long)b * C + c) * H + (py * P + i)) * W + px * P + j;
       float4 f = *reinterpret_cast<const float4*>(src);
-      v = pack4(sat8(f.x * inv_s), sat8(f.y * inv_s), sat8(f.z * inv_s), sat8(f.w * inv_s));
+      v = pack4_sat(rintf(f.x * inv_s), rintf(f.y * inv_s), rintf(f.z * inv_s), rintf(f.w * inv_s));
     }
     *reinterpret_cast<unsigned*>(out + row * k_pad + col) = v;
   }
@@ -244,10 +256,10 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
     y[1] = __builtin_fmaf((float)acc[4 * gq + 1], cs.y, bs.y);
     y[2] = __builtin_fmaf((float)acc[4 * gq + 2], cs.z, bs.z);
     y[3] = __builtin_fmaf((float)acc[4 * gq + 3], cs.w, bs.w);
-    int q[4];
+    float q[4];                 // integral floats; the byte packing below saturates to [-128,127]
     if (EPI == P2V_EPI_REQUANT) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) q[i] = sat8(y[i] * g.ep.inv_s_out);
+      for (int i = 0; i < 4; ++i) q[i] = rintf(y[i] * g.ep.inv_s_out);
     } else if (EPI == P2V_EPI_GELU) {
       gelu_q8x4(y, g.ep.inv_s_out, q);
     } else if (EPI == P2V_EPI_RESID) {
@@ -259,40 +271,36 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
       const float4 rn = *reinterpret_cast<const float4*>(e->r_next + c);
       const float smv[4] = {sm.x, sm.y, sm.z, sm.w}, srv[4] = {sr.x, sr.y, sr.z, sr.w}, snv[4] = {sn.x, sn.y, sn.z, sn.w};
       const float rmv[4] = {rm.x, rm.y, rm.z, rm.w}, rnv[4] = {rn.x, rn.y, rn.z, rn.w};
-      float q3[4], xs[4], qo[4];
-      div_q8fx4(y, smv, rmv, q3);                                      // qact3 / mlp.qact2 (PTF) codes
+      float q3[4], xs[4];
+      div_q8fx4<true>(y, smv, rmv, q3);                                // qact3 / mlp.qact2 (PTF) codes
 #pragma unroll
       for (int i = 0; i < 4; ++i) xs[i] = (float)sx8(res[gq], i) * srv[i] + q3[i] * smv[i];   // x + dequantised branch
-      div_q8fx4(xs, snv, rnv, qo);                                     // Block.qact2 / qact4 (PTF)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) q[i] = (int)qo[i];
+      div_q8fx4<false>(xs, snv, rnv, q);                               // Block.qact2 / qact4 (PTF)
     } else if (EPI == P2V_EPI_EMBED) {
       const float4 sn = *reinterpret_cast<const float4*>(e->s_next + c);
       const float4 rn = *reinterpret_cast<const float4*>(e->r_next + c);
       float4 pe = make_float4(0, 0, 0, 0);
       if (n < g.N) pe = *reinterpret_cast<const float4*>(g.ep.pos_deq + (long long)tok * g.N + n);
       const float snv[4] = {sn.x, sn.y, sn.z, sn.w}, pev[4] = {pe.x, pe.y, pe.z, pe.w}, rnv[4] = {rn.x, rn.y, rn.z, rn.w};
-      float xv[4], qo[4];
+      float xv[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        int q1 = sat8(y[i] * g.ep.inv_s_pe);                  // PatchEmbed.qact
-        int q2 = sat8((float)q1 * g.ep.pe_to_embed);          // qact_embed (both PoT: exact ratio)
-        xv[i] = __builtin_fmaf((float)q2, g.ep.s_embed, pev[i]);   // + qact_pos(pos_embed); int*2^k exact -> one rounding
+        const float q1 = sat8f(y[i] * g.ep.inv_s_pe);               // PatchEmbed.qact
+        const float q2 = sat8f(q1 * g.ep.pe_to_embed);              // qact_embed (both PoT: exact ratio)
+        xv[i] = __builtin_fmaf(q2, g.ep.s_embed, pev[i]);           // + qact_pos(pos_embed); int*2^k exact -> one rounding
       }
-      div_q8fx4(xv, snv, rnv, qo);                            // qact1 (PTF)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) q[i] = (int)qo[i];
+      div_q8fx4<false>(xv, snv, rnv, q);                            // qact1 (PTF)
     } else {  // HEAD: logits fp32 on the act_out grid
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        q[i] = sat8(y[i] * g.ep.inv_s_out);
+        q[i] = sat8f(y[i] * g.ep.inv_s_out);
         if (row_ok && n + i < g.N) {
-          reinterpret_cast<float*>(g.out)[(long long)m * g.ldo + n + i] = (float)q[i] * g.ep.s_out;
-          if (g.out_codes) g.out_codes[(long long)m * g.ldo + n + i] = (int8_t)q[i];
+          reinterpret_cast<float*>(g.out)[(long long)m * g.ldo + n + i] = q[i] * g.ep.s_out;
+          if (g.out_codes) g.out_codes[(long long)m * g.ldo + n + i] = (int8_t)(int)q[i];
         }
       }
     }
-    d[gq] = pack4(q[0], q[1], q[2], q[3]);
+    d[gq] = pack4_sat(q[0], q[1], q[2], q[3]);
     if (EPI == P2V_EPI_RESID || EPI == P2V_EPI_EMBED) __builtin_amdgcn_sched_barrier(0);   // keep the constant reads of the next group from being hoisted (register pressure)
   }
   if (EPI != P2V_EPI_HEAD) {
@@ -696,24 +704,22 @@ __device__ __forceinline__ uint4 gemm_epilogue_tile_res(const v16i& acc, int nl,
     y[1] = __builtin_fmaf((float)acc[4 * gq + 1], k.cs.y, k.bs.y);
     y[2] = __builtin_fmaf((float)acc[4 * gq + 2], k.cs.z, k.bs.z);
     y[3] = __builtin_fmaf((float)acc[4 * gq + 3], k.cs.w, k.bs.w);
-    int q[4];
+    float q[4];
     if (EPI == P2V_EPI_REQUANT) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) q[i] = sat8(y[i] * g.ep.inv_s_out);
+      for (int i = 0; i < 4; ++i) q[i] = rintf(y[i] * g.ep.inv_s_out);
     } else if (EPI == P2V_EPI_GELU) {
       gelu_q8x4(y, g.ep.inv_s_out, q);
     } else {
       const float smv[4] = {k.sm.x, k.sm.y, k.sm.z, k.sm.w}, srv[4] = {k.sr.x, k.sr.y, k.sr.z, k.sr.w};
       const float snv[4] = {k.sn.x, k.sn.y, k.sn.z, k.sn.w}, rmv[4] = {k.rm.x, k.rm.y, k.rm.z, k.rm.w}, rnv[4] = {k.rn.x, k.rn.y, k.rn.z, k.rn.w};
-      float q3[4], xs[4], qo[4];
-      div_q8fx4(y, smv, rmv, q3);
+      float q3[4], xs[4];
+      div_q8fx4<true>(y, smv, rmv, q3);
 #pragma unroll
       for (int i = 0; i < 4; ++i) xs[i] = (float)sx8(res[gq], i) * srv[i] + q3[i] * smv[i];
-      div_q8fx4(xs, snv, rnv, qo);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) q[i] = (int)qo[i];
+      div_q8fx4<false>(xs, snv, rnv, q);
     }
-    d[gq] = pack4(q[0], q[1], q[2], q[3]);
+    d[gq] = pack4_sat(q[0], q[1], q[2], q[3]);
     if (EPI == P2V_EPI_RESID) __builtin_amdgcn_sched_barrier(0);
   }
   return halves_to_row16(d[0], d[1], d[2], d[3]);
@@ -899,7 +905,7 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
     for (int i = 0; i < NCH; ++i) {
       const float g4[4] = {gm[i].x, gm[i].y, gm[i].z, gm[i].w}, b4[4] = {bt[i].x, bt[i].y, bt[i].z, bt[i].w};
       const float i4[4] = {io[i].x, io[i].y, io[i].z, io[i].w}, p4[4] = {pm[i].x, pm[i].y, pm[i].z, pm[i].w};
-      int q[4];
+      float q[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float A = (rs * g4[j]) * i4[j];                            // (s1/std)*gamma / out_scale
@@ -910,9 +916,9 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
         const float sM = copysignf(M, A);                                // A.sign() * M  (M == 0 when A == 0)
         const float Bv = rintf(ldexpf((b4[j] - mos * g4[j]) * i4[j], N));   // layers.py:283-286
         const float o = rintf(ldexpf(sM * xq[i][j] + Bv, -N));           // layers.py:288
-        q[j] = sat8(o * p4[j]);                                          // * out_scale / cs_next / s_next
+        q[j] = rintf(o * p4[j]);                                         // * out_scale / cs_next / s_next (clamped by the packing)
       }
-      outw[i] = pack4(q[0], q[1], q[2], q[3]);
+      outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
     }
     int8_t* dst = a.out + row * a.out_stride;
 #pragma unroll
@@ -1097,7 +1103,7 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt)
         *reinterpret_cast<unsigned*>(dst + dt * 16) =
-            pack4(sat8(o[dt][0] * a.at.av_mul), sat8(o[dt][1] * a.at.av_mul), sat8(o[dt][2] * a.at.av_mul), sat8(o[dt][3] * a.at.av_mul));
+            pack4_sat(rintf(o[dt][0] * a.at.av_mul), rintf(o[dt][1] * a.at.av_mul), rintf(o[dt][2] * a.at.av_mul), rintf(o[dt][3] * a.at.av_mul));
     }
   }
 }
