@@ -438,7 +438,7 @@ __device__ __forceinline__ void gemm_compute_tile_w4(const int8_t* cx, const int
     if (g.stamps && threadIdx.x == 0) g.stamps[(long long)blockIdx.x * 6 + (slot)] = __builtin_readcyclecounter(); \
   } while (0)
 template <int EPI>
-__global__ __launch_bounds__(256, EPI == P2V_EPI_RESID ? 2 : 3) void k_gemm_i8_w4(GemmArgs g) {
+__global__ __launch_bounds__(256, 3) void k_gemm_i8_w4(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) int8_t lds[2 * (GBM + GBN) * GBK + sizeof(EpiLds)];
   int8_t* sX = lds;                    // [2][GBM][GBK] activation rows
   int8_t* sW = lds + 2 * GBM * GBK;    // [2][GBN][GBK] weight rows
