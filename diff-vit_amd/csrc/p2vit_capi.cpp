@@ -25,6 +25,7 @@ static int fail(int code, const char* fmt, ...) {
 }
 static int launch_rc(int rc, const char* what) {
   if (rc == 0) return 0;
+  if (rc == -2) return fail(P2V_E_UNSUPPORTED, "%s: s_qkv_sq * inv_s_attn must be a power of two", what);
   if (rc < 0) return fail(P2V_E_UNSUPPORTED, "%s: no kernel instantiated for this shape", what);
   return fail(P2V_E_LAUNCH, "%s: %s", what, hipGetErrorString((hipError_t)rc));
 }

@@ -940,6 +940,8 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
 //   ~100 VGPRs -> 4 waves/SIMD, 3 workgroups (47 KB LDS each) per CU.
 // ---------------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+typedef short v2i16 __attribute__((ext_vector_type(2)));
 
 template <int HD, int NKP, bool TAP>   // NKP = 32-key pairs covering the tokens (7 for 197); TAP: also write probs_k
 __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
@@ -951,8 +953,9 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int8_t* sK = reinterpret_cast<int8_t*>(smem);                                  // [KROWS][HD] swizzled
   unsigned short* sVt = reinterpret_cast<unsigned short*>(smem + KROWS * HD);    // [HD][VSTRIDE] bf16
-  long long* lutE = reinterpret_cast<long long*>(smem + KROWS * HD + HD * VSTRIDE * 2);  // [257]
-  float* lutF = reinterpret_cast<float*>(lutE + 258);                             // [257]
+  // two 8-byte-stride tables addressed by the same byte offset 8*d: exp_int (int64) and {float(exp_int), 1/float(exp_int)}
+  unsigned char* lutE = smem + KROWS * HD + HD * VSTRIDE * 2;                      // [257] long long
+  unsigned char* lutFR = lutE + 258 * 8;                                           // [257] float2
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x / a.H, head = blockIdx.x % a.H;
@@ -970,11 +973,14 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
     const long long z = (long long)r * (r + a.at.b_int) + a.at.c_int;
     long long e = z << (32 - q);
     e = e < 0 ? 0 : e;
-    lutE[tid] = e;
-    lutF[tid] = (float)e;                        // exact: z < 2^24
+    const float ef = (float)e;                   // exact: z < 2^24; 1 <= e <= 2^56 (z > 0 on (x0, 0], shift >= 0)
+    reinterpret_cast<long long*>(lutE)[tid] = e;
+    // the correctly rounded reciprocal (a bare 1.0f/x may compile to the 1-ulp v_rcp_f32): 1/ef in fp64 is at least
+    // 2^-49 (relative) away from any fp32 rounding boundary, so rounding the fp64 quotient once more is exact
+    reinterpret_cast<float2*>(lutFR)[tid] = make_float2(ef, (float)(1.0 / (double)ef));
     if (tid == 0) {
-      lutE[256] = 0;
-      lutF[256] = 1.0e-30f;                      // sum / 1e-30 -> +inf -> k clamps to 16 -> probability 0
+      reinterpret_cast<long long*>(lutE)[256] = 0;
+      reinterpret_cast<float2*>(lutFR)[256] = make_float2(1.0f, 1.0f);    // sum / 1 >= 2^32 -> k clamps to 16 -> probability 0
     }
   }
   // stage K rows (swizzled so that a 16-row x 16-byte-chunk fragment read is conflict free) and V^T (bf16)
@@ -998,7 +1004,9 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
 
   // (q@k^T)*scale / s_attn  ==  (acc * qk_scale) * (s_q1^2 / s_attn): the power-of-two factors commute with
   // the single rounding of the *scale product (vit_fquant.py:316-317)
-  const float m1 = a.at.qk_scale, m2 = a.at.s_qkv_sq * a.at.inv_s_attn;
+  // s_q1^2 / s_attn is a power of two (checked by the launcher), so ((acc * qk_scale) * 2^e) == acc * (qk_scale * 2^e)
+  // with the same single rounding; the NEGATED code is produced (round-half-even and the clamp are symmetric).
+  const float nmm = -(a.at.qk_scale * (a.at.s_qkv_sq * a.at.inv_s_attn));
   const int nqb = (N + 15) >> 4;
   const int nwaves = (int)(blockDim.x >> 6);
   for (int qb = wave; qb < nqb; qb += nwaves) {
@@ -1016,41 +1024,37 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
       s[kb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq, (v4i){0, 0, 0, 0}, 0, 0, 0);
     }
     const bool tail_empty = (NKB - 1) * 16 >= N;     // last 16-key block holds only padding (e.g. N = 197: keys 208..223)
-    // scores -> int8 codes of qact_attn1 ; row max.  Padded keys (only in the last 32-key pair) get -1000.
-    int mx = -1000;
+    // scores -> NEGATED int8 codes of qact_attn1 (nc = -code) ; row min of nc = -(row max).  Padded keys get +1000.
+    int mn = 1000;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      if (kb == NKB - 1 && tail_empty) {             // wave-uniform: no arithmetic for a block of padding
-        s[kb] = (v4i){-1000, -1000, -1000, -1000};
-        continue;
-      }
+      if (kb == NKB - 1 && tail_empty) continue;       // wave-uniform: no arithmetic for a block of padding
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int c8 = sat8(((float)s[kb][r] * m1) * m2);
-        if (kb >= NKB - 2) c8 = (kb * 16 + 4 * g + r) < N ? c8 : -1000;
-        s[kb][r] = c8;
-        mx = c8 > mx ? c8 : mx;
+        int nc = (int)__builtin_amdgcn_fmed3f(rintf((float)s[kb][r] * nmm), -127.f, 128.f);
+        if (kb >= NKB - 2) nc = (kb * 16 + 4 * g + r) < N ? nc : 1000;
+        s[kb][r] = nc;
+        mn = nc < mn ? nc : mn;
       }
     }
     {
-      int o = __shfl_xor(mx, 16);
-      mx = o > mx ? o : mx;
-      o = __shfl_xor(mx, 32);
-      mx = o > mx ? o : mx;
+      int o = __shfl_xor(mn, 16);
+      mn = o < mn ? o : mn;
+      o = __shfl_xor(mn, 32);
+      mn = o < mn ? o : mn;
     }
+    // d = max - code = nc - mn in [0, 255]; s[][] := 8*d, the byte offset into both tables (256 = sentinel of padding)
+    const int neg8mn = -8 * mn;
     long long S = 0;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      if (kb == NKB - 1 && tail_empty) {
-        s[kb] = (v4i){256, 256, 256, 256};
-        continue;
-      }
+      if (kb == NKB - 1 && tail_empty) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int d = mx - s[kb][r];
-        if (kb >= NKB - 2) d = d > 256 ? 256 : d;               // sentinel entry
-        s[kb][r] = d;
-        S += lutE[d];
+        int d8 = (s[kb][r] << 3) + neg8mn;
+        if (kb >= NKB - 2) d8 = d8 > 2048 ? 2048 : d8;
+        s[kb][r] = d8;
+        S += *reinterpret_cast<const long long*>(lutE + d8);
       }
       __builtin_amdgcn_sched_barrier(0);                         // keep live ranges short
     }
@@ -1066,24 +1070,35 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
       unsigned pk[4];
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
-        unsigned hw2[2];
+        float ratio[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int j = 2 * e2 + e;                              // element of the 8-wide B fragment
           const int kb = 2 * p + (j >> 2), r = j & 3;
-          const int d = s[kb][r];
           if (kb == NKB - 1 && tail_empty) {                     // (compile-time kb, wave-uniform flag)
-            hw2[e] = 0u;
+            ratio[e] = 4.0e9f;                                   // -> probability 0
             continue;
           }
-          const float ratio = rintf(Sf / lutF[d]);              // round(sum / exp_int), layers.py:370
-          int k = (int)((__float_as_uint(ratio) + 0x00400000u) >> 23) - 127;   // log_round, layers.py:323-329
-          k = k > 16 ? 16 : k;                                   // ratio >= 1, so k >= 0
-          hw2[e] = k < 16 ? (unsigned)(127 - k) << 7 : 0u;       // 2^-k as bf16; k>=16 -> 0 (layers.py:372-375)
-          if (TAP && d < 256 && qrow < N)
-            a.probs_k[(((long long)b * a.H + head) * N + qrow) * N + kb * 16 + 4 * g + r] = (int8_t)k;
+          // round(sum / exp_int), layers.py:370.  Both operands are normal and the quotient is in [1, 2^65): no scaling
+          // or fix-up is needed, and with R the correctly rounded reciprocal two FMA corrections give the correctly
+          // rounded quotient (q1 is faithful; Markstein's theorem for q2).
+          const float2 fr = *reinterpret_cast<const float2*>(lutFR + s[kb][r]);
+          const float q0 = Sf * fr.y;
+          const float q1 = __builtin_fmaf(__builtin_fmaf(-fr.x, q0, Sf), fr.y, q0);
+          const float q2 = __builtin_fmaf(__builtin_fmaf(-fr.x, q1, Sf), fr.y, q1);
+          ratio[e] = rintf(q2);
+          if (TAP && s[kb][r] < 2048 && qrow < N) {
+            int k = (int)((__float_as_uint(ratio[e]) + 0x00400000u) >> 23) - 127;   // log_round, layers.py:323-329
+            a.probs_k[(((long long)b * a.H + head) * N + qrow) * N + kb * 16 + 4 * g + r] = (int8_t)(k > 16 ? 16 : k);
+          }
         }
-        pk[e2] = hw2[0] | (hw2[1] << 16);
+        // log_round on the two high halves at once: E = (bits + 0x00400000) >> 23 is the biased exponent of 2^k
+        // (ratio >= 1 so k >= 0); 2^-k as bf16 is (254 - E) << 7, and k >= 16 (E >= 143) -> 0   (layers.py:372-375)
+        const unsigned hi2 = __builtin_amdgcn_perm(__float_as_uint(ratio[1]), __float_as_uint(ratio[0]), 0x07060302u);
+        const v2u16 eb = __builtin_bit_cast(v2u16, (__builtin_bit_cast(unsigned, __builtin_bit_cast(v2u16, hi2) + (v2u16){0x40, 0x40})) & 0x7F807F80u);
+        const v2u16 hb = (v2u16){0x7F00, 0x7F00} - eb;                                  // (254 - E) << 7
+        const v2i16 neg = __builtin_bit_cast(v2i16, (v2u16)(hb - (v2u16){0x3800, 0x3800})) >> (v2i16){15, 15};   // all ones where k >= 16
+        pk[e2] = __builtin_bit_cast(unsigned, hb) & ~__builtin_bit_cast(unsigned, neg);
       }
       v4i pb = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
       const v8bf fb = __builtin_bit_cast(v8bf, pb);
@@ -1300,7 +1315,7 @@ int p2v_launch_layernorm(const LnArgs& a, hipStream_t st) {
 template <int HD, int NKB>
 static int launch_attn_t(const AttnArgs& a, hipStream_t st) {
   constexpr int KROWS = NKB * 32;   // NKB here = 32-key pairs
-  constexpr size_t smem = (size_t)KROWS * HD + (size_t)HD * (KROWS + 4) * 2 + 258 * 8 + 260 * 4;
+  constexpr size_t smem = (size_t)KROWS * HD + (size_t)HD * (KROWS + 4) * 2 + 258 * 8 + 258 * 8;
   if (a.probs_k)
     hipLaunchKernelGGL((k_lis_attention<HD, NKB, true>), dim3(a.B * a.H), dim3(64 * g_attn_waves), smem, st, a);
   else
@@ -1311,6 +1326,11 @@ static int launch_attn_t(const AttnArgs& a, hipStream_t st) {
 
 int p2v_launch_attention(const AttnArgs& a, int head_dim, hipStream_t st) {
   const int nkb = (a.N + 31) / 32;
+  {   // the kernel folds s_q1^2 / s_attn into qk_scale: exact only for a power of two (both are PoT scales in the reference)
+    int ex;
+    const float m2 = a.at.s_qkv_sq * a.at.inv_s_attn;
+    if (!(m2 > 0.f) || frexpf(m2, &ex) != 0.5f) return -2;
+  }
   if (head_dim == 64) {
     switch (nkb) {
       case 1: return launch_attn_t<64, 1>(a, st);
