@@ -53,6 +53,8 @@ extern "C" {
 
 extern int g_use_panel;
 extern int g_gemm_waves;
+extern int g_ln_generic;
+extern int g_ln_rows;
 extern int g_attn_waves;
 extern unsigned long long* g_gemm_stamps;
 extern int g_gemm_stagger;
@@ -72,6 +74,10 @@ static void read_env_once() {
   if (e) g_gemm_stagger = atoi(e);
   e = getenv("P2V_ATTN_WAVES");
   if (e && atoi(e) >= 4 && atoi(e) <= 8) g_attn_waves = atoi(e);
+  e = getenv("P2V_LN_ROWS");
+  if (e && atoi(e) >= 1 && atoi(e) <= 64) g_ln_rows = atoi(e);
+  e = getenv("P2V_LN_GENERIC");
+  if (e && atoi(e) == 1) g_ln_generic = 1;
   e = getenv("P2V_GEMM_DBG");
   if (e) g_gemm_dbg = atoi(e);
 }

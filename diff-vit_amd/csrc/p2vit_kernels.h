@@ -32,6 +32,8 @@ struct LnArgs {
   p2v_ln ln;
   int8_t* out;
   long long out_stride;
+  int rows_per_half;    // filled by the launcher: consecutive rows per 32-lane half wave
+  int force_generic;    // filled by the launcher (P2V_LN_GENERIC=1: A/B and parity runs of the generic chain)
 };
 
 struct AttnArgs {

@@ -19,6 +19,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------------
 // small device helpers
@@ -840,40 +841,135 @@ __global__ __launch_bounds__(1024, 4) void k_gemm_resident(GemmArgs g, int tiles
 // wave so the five per-channel constant vectors stay in registers.  sum x and sum x^2 are exact integers;
 // everything after mirrors the reference's fp32 operation order.
 // ---------------------------------------------------------------------------------------------------
-#define LN_ROWS 2
+// sum over the 32 lanes of a half wave, result in every lane: four DPP butterflies (no address registers, VALU rate) and
+// one ds_swizzle for the distance-16 step.  After the xor-1/xor-2 steps the four lanes of a quad agree, so the mirrors
+// of 8 and 16 lanes act as xor-4 and xor-8.
+__device__ __forceinline__ int half_wave_sum(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror
+  v += __builtin_amdgcn_ds_swizzle(v, 0x401F);                      // bitmask mode: lane ^ 16
+  return v;
+}
+
+// generic per-element chain: every step of get_MN / the 'int' forward as written in the reference
+__device__ __forceinline__ float ln_elem_generic(float xq, float g, float bta, float io, float pm, float rs, float mos) {
+  const float A = (rs * g) * io;                                   // (s1/std)*gamma / out_scale
+  const float absA = fabsf(A);
+  int N = 134 - (int)(__float_as_uint(absA) >> 23);                // 7 - floor(log2|A|)   (get_MN, layers.py:234-238)
+  N = N < 0 ? 0 : (N > 31 ? 31 : N);
+  const float M = fminf(floorf(ldexpf(absA, N)), 255.f);           // floor(|A| * 2^N), clamped
+  const float sM = copysignf(M, A);                                // A.sign() * M  (M == 0 when A == 0)
+  const float Bv = rintf(ldexpf((bta - mos * g) * io, N));         // layers.py:283-286
+  const float o = rintf(ldexpf(sM * xq + Bv, -N));                 // layers.py:288
+  return rintf(o * pm);                                            // * out_scale / cs_next / s_next (clamped by the packing)
+}
+
+// Fast chain (used when 1/out_scale is a power of two for every channel, which is the P2-ViT case, and the row's
+// multipliers are inside the unclamped range of get_MN).  With io = 2^e:  A = (rs*g)*io = rs*(g*io)  and
+// (b - mos*g)*io = b*io - mos*(g*io)  with the same roundings, so g*io and b*io are folded once per workgroup (shared
+// through LDS).  For 2^-24 <= |A| < 2^8:  N = 134 - exp(A) is unclamped and M = floor(|A| 2^N) in [128,255] is the top
+// 8 significant bits of A, i.e.  sign*M*2^-N == A with the low 16 mantissa bits cleared =: T;  and
+// rint(((sM*xq + Bv) rounded) * 2^-N) == rint(fma(T, xq, Bv*2^-N))  because T*xq is exact (8 x 11 bits) and scaling by
+// 2^-N commutes with the rounding.  Bit-identical to the generic chain (tests drive both through P2V_LN_GENERIC=1).
 template <int NCH>
 __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
+  // per-channel constants are folded once per workgroup, shared through LDS, then held in registers (re-reading them from
+  // LDS per row frees 46 VGPRs but measured 10 % slower: the kernel is bound by VALU issue, not by occupancy)
+  __shared__ __attribute__((aligned(16))) float sG[NCH * 128], sB[NCH * 128], sP[NCH * 128];
+  __shared__ __attribute__((aligned(16))) int sM[NCH * 128];
   const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
-  float4 mk[NCH], gm[NCH], bt[NCH], io[NCH], pm[NCH];
+  int potf = a.force_generic ? 0 : 1;
+  if (tid < NCH * 32) {   // one thread per 4 channels: fold, test, and publish
+    const int c = tid * 4;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), b = g, io = make_float4(1.f, 1.f, 1.f, 1.f), pmv = g, mk = g;
+    if (c < a.C) {
+      g = *reinterpret_cast<const float4*>(a.ln.gamma + c);
+      b = *reinterpret_cast<const float4*>(a.ln.beta + c);
+      io = *reinterpret_cast<const float4*>(a.ln.inv_out + c);
+      pmv = *reinterpret_cast<const float4*>(a.ln.post_mul + c);
+      mk = *reinterpret_cast<const float4*>(a.ln.mask + c);
+    }
+    const float g4[4] = {g.x, g.y, g.z, g.w}, b4[4] = {b.x, b.y, b.z, b.w}, i4[4] = {io.x, io.y, io.z, io.w};
+    float go[4], bo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned ib = __float_as_uint(i4[j]);
+      const int p2 = (int)((ib & 0x807FFFFFu) == 0u) & (int)((ib >> 23) - 32u <= 190u);    // +2^e, far from under/overflow
+      go[j] = g4[j] * i4[j];
+      bo[j] = b4[j] * i4[j];
+      const float ga = fabsf(go[j]), ba = fabsf(bo[j]);
+      // the fold must be exact: no product may leave the normal range
+      const int gok = (int)(g4[j] == 0.f) | ((int)(ga >= 1.0e-30f) & (int)(ga <= 1.0e30f));
+      const int bok = (int)(b4[j] == 0.f) | ((int)(ba >= 1.0e-30f) & (int)(ba <= 1.0e30f));
+      potf &= p2 & gok & bok;
+    }
+    *reinterpret_cast<float4*>(sG + c) = make_float4(go[0], go[1], go[2], go[3]);
+    *reinterpret_cast<float4*>(sB + c) = make_float4(bo[0], bo[1], bo[2], bo[3]);
+    *reinterpret_cast<float4*>(sP + c) = pmv;
+    *reinterpret_cast<int4*>(sM + c) = make_int4((int)mk.x, (int)mk.y, (int)mk.z, (int)mk.w);
+  }
+  const bool pot = __syncthreads_and(potf) != 0;
   bool on[NCH];
+  float4 gm[NCH], bt[NCH], pm[NCH];
+  int4 mki[NCH];
+  // extreme |g io| over all channels (every half wave covers all of them)
+  float gmin = 3.0e38f, gmax = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    int c = (l32 + 32 * i) * 4;
+    const int c = (l32 + 32 * i) * 4;
     on[i] = c < a.C;
-    int cc = on[i] ? c : 0;
-    mk[i] = *reinterpret_cast<const float4*>(a.ln.mask + cc);
-    gm[i] = *reinterpret_cast<const float4*>(a.ln.gamma + cc);
-    bt[i] = *reinterpret_cast<const float4*>(a.ln.beta + cc);
-    io[i] = *reinterpret_cast<const float4*>(a.ln.inv_out + cc);
-    pm[i] = *reinterpret_cast<const float4*>(a.ln.post_mul + cc);
+    const float4 gv = *reinterpret_cast<const float4*>(sG + c);
+    gm[i] = gv;
+    bt[i] = *reinterpret_cast<const float4*>(sB + c);
+    pm[i] = *reinterpret_cast<const float4*>(sP + c);
+    mki[i] = *reinterpret_cast<const int4*>(sM + c);
+    const float lo = fminf(fminf(fabsf(gv.x), fabsf(gv.y)), fminf(fabsf(gv.z), fabsf(gv.w)));
+    const float hi = fmaxf(fmaxf(fabsf(gv.x), fabsf(gv.y)), fmaxf(fabsf(gv.z), fabsf(gv.w)));
+    gmin = fminf(gmin, on[i] ? lo : 3.0e38f);
+    gmax = fmaxf(gmax, on[i] ? hi : 0.f);
+  }
+  {   // positive floats order like their bit patterns: integer min/max butterflies inside the half wave
+    int lo = (int)__float_as_uint(gmin), hi = (int)__float_as_uint(gmax);
+#define LN_MM(ctrl) lo = min(lo, __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false)); hi = max(hi, __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false));
+    LN_MM(0xB1) LN_MM(0x4E) LN_MM(0x141) LN_MM(0x140)
+#undef LN_MM
+    lo = min(lo, __builtin_amdgcn_ds_swizzle(lo, 0x401F));
+    hi = max(hi, __builtin_amdgcn_ds_swizzle(hi, 0x401F));
+    gmin = __uint_as_float((unsigned)lo);
+    gmax = __uint_as_float((unsigned)hi);
   }
   const float s1 = a.ln.s1;
   const float Cf = (float)a.C;
+  const float s1oC = s1 / Cf;
+  const int LN_ROWS = a.rows_per_half;
   const long long row0 = ((long long)blockIdx.x * 8 + hw) * LN_ROWS;
+  // Row r+1 is requested at the top of the iteration of row r and first touched just before the stores of row r.  The two
+  // empty asm statements pin that placement: left alone, hipcc sinks the loads of a loop-carried value to the loop end,
+  // behind the stores, and waits vmcnt(0) there - two exposed memory round trips per row (measured: 3 us per row).
+  int colofs[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) colofs[i] = on[i] ? (l32 + 32 * i) * 4 : 0;     // clamped: loads are unconditional
+  const long long last_row = a.rows - 1;
   unsigned wnext[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
-    wnext[i] = (on[i] && row0 < a.rows) ? *reinterpret_cast<const unsigned*>(a.x + row0 * a.row_stride + (l32 + 32 * i) * 4) : 0u;
+    wnext[i] = *reinterpret_cast<const unsigned*>(a.x + (row0 < a.rows ? row0 : last_row) * a.row_stride + colofs[i]);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(wnext[i]));   // first row landed: no wait is merged into the loop head
+#pragma unroll 1
   for (int rr = 0; rr < LN_ROWS; ++rr) {
     const long long row = row0 + rr;
-    if (row >= a.rows) break;   // uniform within the half wave; shuffles below use width 32
+    if (row >= a.rows) break;   // uniform within the half wave; the reductions below stay inside 32 lanes
     unsigned wcur[NCH];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) wcur[i] = wnext[i];
-    if (rr + 1 < LN_ROWS && row + 1 < a.rows) {   // request the next row before the arithmetic of this one
+    for (int i = 0; i < NCH; ++i) wcur[i] = on[i] ? wnext[i] : 0u;
+    {
+      const long long nrow = row + 1 < a.rows ? row + 1 : last_row;
 #pragma unroll
-      for (int i = 0; i < NCH; ++i)
-        if (on[i]) wnext[i] = *reinterpret_cast<const unsigned*>(a.x + (row + 1) * a.row_stride + (l32 + 32 * i) * 4);
+      for (int i = 0; i < NCH; ++i) wnext[i] = *reinterpret_cast<const unsigned*>(a.x + nrow * a.row_stride + colofs[i]);
+      asm volatile("" ::: "memory");                 // the loads stay above this line
     }
     float xq[NCH][4];
     int S1 = 0;
@@ -881,45 +977,67 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const unsigned w = wcur[i];
-      const float m4[4] = {mk[i].x, mk[i].y, mk[i].z, mk[i].w};
+      const int m4[4] = {mki[i].x, mki[i].y, mki[i].z, mki[i].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int v = on[i] ? __mul24(sx8(w, j), (int)m4[j]) : 0;   // x_q * in_scale_mask  (layers.py:269-273)
+        const int v = __mul24(sx8(w, j), m4[j]);           // x_q * in_scale_mask  (layers.py:269-273); w == 0 past C
         xq[i][j] = (float)v;
         S1 += v;
         S2 += __mul24(v, v);
       }
     }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-      S1 += __shfl_xor(S1, o, 32);
-      S2 += __shfl_xor(S2, o, 32);
-    }
+    S1 = half_wave_sum(S1);
+    S2 = half_wave_sum(S2);
     const float S1f = (float)S1, S2f = (float)S2;
     const float mean = (S1f / Cf) * s1;                                  // x_q.mean(-1) * in_scale1
-    const float stdv = (s1 / Cf) * sqrtf(Cf * S2f - S1f * S1f);          // layers.py:276-277
+    const float stdv = s1oC * sqrtf(Cf * S2f - S1f * S1f);               // layers.py:276-277
     const float rs = s1 / stdv;
     const float mos = mean / stdv;
     unsigned outw[NCH];
+    // |A| = RN(rs*|g io|) is monotone in |g io|: the two extreme channels bound every channel exactly
+    const bool fast = pot && rs * gmin >= 0x1p-24f && rs * gmax < 256.f;
+    if (fast) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const float g4[4] = {gm[i].x, gm[i].y, gm[i].z, gm[i].w}, b4[4] = {bt[i].x, bt[i].y, bt[i].z, bt[i].w};
-      const float i4[4] = {io[i].x, io[i].y, io[i].z, io[i].w}, p4[4] = {pm[i].x, pm[i].y, pm[i].z, pm[i].w};
-      float q[4];
+      for (int i = 0; i < NCH; ++i) {
+        const float g4[4] = {gm[i].x, gm[i].y, gm[i].z, gm[i].w}, b4[4] = {bt[i].x, bt[i].y, bt[i].z, bt[i].w};
+        const float p4[4] = {pm[i].x, pm[i].y, pm[i].z, pm[i].w};
+        float q[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float A = (rs * g4[j]) * i4[j];                            // (s1/std)*gamma / out_scale
-        const float absA = fabsf(A);
-        int N = 134 - (int)(__float_as_uint(absA) >> 23);                // 7 - floor(log2|A|)   (get_MN, layers.py:234-238)
-        N = N < 0 ? 0 : (N > 31 ? 31 : N);
-        const float M = fminf(floorf(ldexpf(absA, N)), 255.f);           // floor(|A| * 2^N), clamped
-        const float sM = copysignf(M, A);                                // A.sign() * M  (M == 0 when A == 0)
-        const float Bv = rintf(ldexpf((b4[j] - mos * g4[j]) * i4[j], N));   // layers.py:283-286
-        const float o = rintf(ldexpf(sM * xq[i][j] + Bv, -N));           // layers.py:288
-        q[j] = rintf(o * p4[j]);                                         // * out_scale / cs_next / s_next (clamped by the packing)
+        for (int j = 0; j < 4; j += 2) {   // two channels at a time: the multiplies, the subtraction and the fma are v_pk_*_f32
+          const v2f g2 = {g4[j], g4[j + 1]}, b2 = {b4[j], b4[j + 1]}, p2 = {p4[j], p4[j + 1]}, x2 = {xq[i][j], xq[i][j + 1]};
+          const v2f A2 = (v2f){rs, rs} * g2;
+          const v2f t2 = b2 - (v2f){mos, mos} * g2;
+          v2f T2, Bq2;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const unsigned Ab = __float_as_uint(A2[e]);
+            T2[e] = __uint_as_float(Ab & 0xFFFF0000u);                              // sign * M * 2^-N
+            const int N = 134 - (int)((Ab >> 23) & 255u);                           // in [0, 31] by the range test
+            Bq2[e] = ldexpf(rintf(ldexpf(t2[e], N)), -N);                           // Bv * 2^-N
+          }
+          const v2f o2 = __builtin_elementwise_fma(T2, x2, Bq2);
+          const v2f q2 = (v2f){rintf(o2[0]), rintf(o2[1])} * p2;
+          q[j] = rintf(q2[0]);
+          q[j + 1] = rintf(q2[1]);
+        }
+        outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
       }
-      outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int cc = on[i] ? (l32 + 32 * i) * 4 : 0;
+        const float4 gv = *reinterpret_cast<const float4*>(a.ln.gamma + cc), bv = *reinterpret_cast<const float4*>(a.ln.beta + cc);
+        const float4 iv = *reinterpret_cast<const float4*>(a.ln.inv_out + cc), pv = *reinterpret_cast<const float4*>(a.ln.post_mul + cc);
+        const float g4[4] = {gv.x, gv.y, gv.z, gv.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
+        const float i4[4] = {iv.x, iv.y, iv.z, iv.w}, p4[4] = {pv.x, pv.y, pv.z, pv.w};
+        float q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = ln_elem_generic(xq[i][j], g4[j], b4[j], i4[j], p4[j], rs, mos);
+        outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
+      }
     }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(wnext[i]));   // the wait for row r+1 lands here, ahead of the stores
     int8_t* dst = a.out + row * a.out_stride;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
@@ -1295,7 +1413,13 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   return 0;
 }
 
-int p2v_launch_layernorm(const LnArgs& a, hipStream_t st) {
+int g_ln_generic = 0;     // P2V_LN_GENERIC=1
+int g_ln_rows = 4;        // P2V_LN_ROWS: consecutive rows per half wave
+int p2v_launch_layernorm(const LnArgs& a_, hipStream_t st) {
+  LnArgs a = a_;
+  a.force_generic = g_ln_generic;
+  a.rows_per_half = g_ln_rows;
+  const int LN_ROWS = g_ln_rows;
   const int nch = (a.C + 127) / 128;
   const int rows_per_block = 8 * LN_ROWS;
   dim3 grid((unsigned)((a.rows + rows_per_block - 1) / rows_per_block)), block(256);
