@@ -11,6 +11,7 @@ Input is a *calibration dict* (nested: name -> tensor | {bit_name: tensor} | [pe
 the format ``export_calib`` produces from the module surface; plus the fp32 ``state_dict``.
 """
 import ctypes as C
+import weakref
 import math
 
 import numpy as np
@@ -71,6 +72,13 @@ class FrozenPlan:
         E.check(L.p2v_plan_create(C.byref(desc), C.byref(self._handle)))
         W = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         self._build(W, calib)
+        from . import ops                      # torch.ops.p2vit.forward(handle, images, bit_config)
+        ops._PLANS[self.handle] = weakref.proxy(self)
+
+    @property
+    def handle(self):
+        """integer value of the C plan pointer (the ``plan`` argument of ``torch.ops.p2vit.forward``)."""
+        return int(self._handle.value or 0)
 
     # ---------------------------------------------------------------------------------------------
     def _dev(self, t, dtype=torch.float32):
@@ -293,6 +301,11 @@ class FrozenPlan:
         return self._ws[off: off + rows * cols].view(torch.int8).reshape(rows, cols)
 
     def __del__(self):
+        try:
+            from . import ops
+            ops._PLANS.pop(int(self._handle.value or 0), None)
+        except Exception:
+            pass
         try:
             if self._handle:
                 E.lib().p2v_plan_destroy(self._handle)

@@ -45,3 +45,15 @@ def test_error_conventions_without_gpu():
     rc = L.p2v_forward(h, ctypes.c_void_p(1), 1, cfg, 49, ctypes.c_void_p(1), ctypes.c_void_p(1), 0, -1, None)
     assert rc == E.E_BITS                                                 # wrong bit_config length
     L.p2v_plan_destroy(h)
+
+
+def test_custom_ops_registered_and_gpu_only():
+    """torch.ops.p2vit.* exist after import and have no CPU kernel (no silent fallback)."""
+    import torch
+    import diff_vit_amd as dva
+    for name in dva.ops.OPS:
+        assert hasattr(torch.ops.p2vit, name), name
+    with pytest.raises(NotImplementedError):
+        torch.ops.p2vit.fake_quant(torch.zeros(4), torch.ones(1), 1, -128, 127)
+    with pytest.raises(NotImplementedError):
+        torch.ops.p2vit.int_layernorm(torch.zeros(2, 64, dtype=torch.int8), 1.0, *[torch.ones(64)] * 5)

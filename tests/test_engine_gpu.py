@@ -361,3 +361,27 @@ def test_other_configs_engine_vs_oracle(dva, oracle, name, bits):
         ref = orc.quant_forward(x, bc)
         assert torch.equal(out.cpu(), ref), (name, bc[:6], int((out.cpu() != ref).sum()))
         assert flops == orc.flops()
+
+
+def test_custom_ops_match_c_abi(dva, oracle, micro):
+    """torch.ops.p2vit.*  are the same entry points: compare against the oracle / the plan."""
+    S = dva.synth
+    M, K, N = 200, 128, 192
+    x = _rand_codes(S, 7, 'ox', (M, K)); w = _rand_codes(S, 7, 'ow', (N, K), 30.0)
+    bias = S.normal(7, 'ob', (N,), 0.4)
+    s_x, s_w = 2.0 ** -5, torch.full((N,), 2.0 ** -7)
+    y = oracle.qgemm(x, torch.tensor(s_x), w, s_w, bias)
+    got = torch.ops.p2vit.linear_requant(x.to(torch.int8).cuda(), w.to(torch.int8).cuda(), (s_x * s_w).cuda(), bias.cuda(), 8.0)
+    assert torch.equal(got.cpu().float(), torch.clamp(torch.round(y / 0.125), -128, 127))
+    got = torch.ops.p2vit.linear_gelu_requant(x.to(torch.int8).cuda(), w.to(torch.int8).cuda(), (s_x * s_w).cuda(), bias.cuda(), 32.0)
+    assert torch.equal(got.cpu().float(), torch.clamp(torch.round(oracle.gelu_rn(y) * 32.0), -128, 127))
+    v = S.normal(7, 'of', (3, 5, 64), 2.0); sc = 2.0 ** torch.floor(S.uniform(7, 'os', (64,), -6, -3))
+    fq = torch.ops.p2vit.fake_quant(v.cuda(), sc.cuda(), 1, -128, 127)
+    assert torch.equal(fq.cpu(), oracle.fake_quant(v, sc.reshape(1, 1, -1), -128, 127))
+    plan = dva.FrozenPlan(micro['arch'], micro['sd'], micro['calib'])
+    xi = micro['x_ev'].cuda()
+    bits = [8] * (4 * micro['arch']['depth'] + 2)
+    out = torch.ops.p2vit.forward(plan.handle, xi, bits)
+    assert np.array_equal(out.cpu().numpy(), micro['g']['logits/q8'])
+    with pytest.raises(RuntimeError):
+        torch.ops.p2vit.forward(12345, xi, bits)
