@@ -362,6 +362,24 @@ int p2v_lis_attention(const int8_t* qkv, int batch, int tokens, int heads, int h
   return launch_rc(p2v_launch_attention(a, head_dim, (hipStream_t)stream), "lis_attention");
 }
 
+int p2v_window_attention(const int8_t* qkv, int batch, int tokens_per_image, int heads, int head_dim, const p2v_winattn* wa,
+                         int8_t* out, int8_t* probs_k, void* stream) {
+  if (!qkv || !wa || !out || !wa->table_codes || !wa->win_index) return fail(P2V_E_ARG, "p2v_window_attention: null argument");
+  if (batch <= 0 || tokens_per_image <= 0 || heads <= 0) return fail(P2V_E_SHAPE, "bad window attention shape");
+  if (head_dim != 32) return fail(P2V_E_UNSUPPORTED, "window attention: head_dim must be 32");
+  if (wa->ws < 1 || wa->ws > 8 || wa->n_windows < 1 || wa->ws * wa->ws * wa->n_windows > tokens_per_image)
+    return fail(P2V_E_SHAPE, "window attention: window size must be 1..8 and windows must fit the token count");
+  if (wa->x0_int >= 0) return fail(P2V_E_ARG, "x0_int must be negative");
+  const float pots[5] = {wa->s_q1, wa->s_attn, wa->s_table, wa->s_q2, wa->s_q3};
+  for (float s : pots) {
+    int ex;
+    if (!(s > 0.f) || frexpf(s, &ex) != 0.5f) return fail(P2V_E_UNSUPPORTED, "window attention: activation scales must be powers of two");
+  }
+  if (wa->s_q2 > 1.0f) return fail(P2V_E_UNSUPPORTED, "window attention: qact2 scale above 1 (the -100 mask would not be an integer)");
+  WinAttnArgs a{qkv, batch, tokens_per_image, heads, *wa, out, probs_k};
+  return launch_rc(p2v_launch_window_attention(a, (hipStream_t)stream), "window_attention");
+}
+
 int p2v_fake_quant_f32(const float* x, long long n, const float* scale, int n_scale, long long inner, int lo, int hi, float* out,
                        int8_t* codes, void* stream) {
   if (!x || !scale || (!out && !codes)) return fail(P2V_E_ARG, "p2v_fake_quant_f32: null argument");

@@ -44,6 +44,15 @@ struct AttnArgs {
   int8_t* probs_k;
 };
 
+struct WinAttnArgs {
+  const int8_t* qkv;
+  int B, T, H;          // images, tokens per image, heads
+  p2v_winattn wa;
+  int8_t* out;
+  int8_t* probs_k;
+};
+int p2v_launch_window_attention(const WinAttnArgs& a, hipStream_t st);
+
 int p2v_launch_patchify(const float* img, int B, int C, int H, int W, int P, float inv_s, int8_t* out, int k_pad, hipStream_t st);
 int p2v_launch_fill_cls(int8_t* x, int B, int T, int D, const int8_t* cls, hipStream_t st);
 int p2v_launch_gemm(int epi, const GemmArgs& g, hipStream_t st);

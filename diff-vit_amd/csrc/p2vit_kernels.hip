@@ -1242,6 +1242,127 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K4: Swin window attention core (swin_quant.py:186-217, 366-391), head_dim 32, windows of ws*ws <= 64 tokens.
+//   One wave per (image, window, head); lane j is key/value token j of the window.  The reference multiplies the dequantised
+//   q by head_dim^-0.5 (not a power of two at head_dim 32) BEFORE the dot product, so the scores are sums of products of
+//   arbitrary fp32 values and 8-bit codes: the lane keeps its key as 32 doubles and accumulates v_fma_f64 (products have
+//   <= 32 significant bits, sums of 32 of them < 2^53: exact), then rounds once to fp32 - the canonical reading of the fp32
+//   matmul.  Window partition, cyclic shift and their inverses are a row-index table; the shifted-window mask is a region-id
+//   table (different regions -> -100, which after the clamp at 32*x0 is table entry 256; padding lanes use the zero entry 257).
+//   P.V runs with lane = channel (two half waves split the keys), exact in fp32 (sum P <= 1.5, values multiples of 2^-15).
+// ---------------------------------------------------------------------------------------------------
+#define WA_HD 32
+#define WA_MAXN 64
+__global__ __launch_bounds__(256) void k_window_attention(WinAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sQ[4][WA_MAXN * WA_HD];     // RN32((q*s1)*scale)
+  __shared__ __attribute__((aligned(16))) float sV[4][WA_MAXN * WA_HD];     // v codes
+  __shared__ float sP[4][WA_MAXN];
+  __shared__ int8_t sT[4][232];                                              // bias-table column of the head ((2*8-1)^2 = 225 max)
+  __shared__ long long lutE[258];
+  __shared__ float2 lutFR[258];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ws = a.wa.ws, N = ws * ws, nW = a.wa.n_windows;
+  const int hgroups = (a.H + 3) >> 2;
+  const int blk = blockIdx.x;
+  const int hg = blk % hgroups, w = (blk / hgroups) % nW, b = blk / (hgroups * nW);
+  const int head = hg * 4 + wave;
+  const int C = a.H * WA_HD;
+  // exp table of the log-int-softmax (as in k_lis_attention); entry 256 = clamp value (masked pairs), 257 = padding
+  for (int t = tid; t < 258; t += (int)blockDim.x) {
+    int xi = -t;
+    const int lim = 32 * a.wa.x0_int;
+    xi = (xi < lim || t >= 256) ? lim : xi;
+    const int q = xi / a.wa.x0_int;
+    const int r = xi - a.wa.x0_int * q;
+    const long long z = (long long)r * (r + a.wa.b_int) + a.wa.c_int;
+    long long e = z << (32 - q);
+    e = e < 0 ? 0 : e;
+    if (t == 257) e = 0;
+    const float ef = t == 257 ? 1.0f : (float)e;
+    lutE[t] = e;
+    lutFR[t] = make_float2(ef, (float)(1.0 / (double)ef));
+  }
+  __syncthreads();
+  if (head >= a.H) return;
+  const int tsz = (2 * ws - 1) * (2 * ws - 1);
+  for (int t = lane; t < tsz; t += 64) sT[wave][t] = a.wa.table_codes[t * a.H + head];
+  const bool live = lane < N;
+  const int j = live ? lane : N - 1;
+  const int rowj = a.wa.win_index[w * N + j];
+  const int8_t* base = a.qkv + ((long long)b * a.T + rowj) * 3 * C + head * WA_HD;
+  const uint4 q0 = *reinterpret_cast<const uint4*>(base), q1 = *reinterpret_cast<const uint4*>(base + 16);
+  const uint4 k0 = *reinterpret_cast<const uint4*>(base + C), k1 = *reinterpret_cast<const uint4*>(base + C + 16);
+  const uint4 v0 = *reinterpret_cast<const uint4*>(base + 2 * C), v1 = *reinterpret_cast<const uint4*>(base + 2 * C + 16);
+  const unsigned qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+  const unsigned kw[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+  const unsigned vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  double kd[WA_HD];
+#pragma unroll
+  for (int c = 0; c < WA_HD; ++c) {
+    kd[c] = (double)sx8(kw[c >> 2], c & 3);
+    sQ[wave][lane * WA_HD + c] = ((float)sx8(qw[c >> 2], c & 3) * a.wa.s_q1) * a.wa.qk_scale;   // one rounding (s_q1 is 2^e)
+    sV[wave][lane * WA_HD + c] = (float)sx8(vw[c >> 2], c & 3);
+  }
+  const int regj = a.wa.region ? (int)a.wa.region[w * N + j] : 0;
+  const int jy = j / ws, jx = j % ws;
+  const float inv_sa = 1.0f / a.wa.s_attn, inv_s2 = 1.0f / a.wa.s_q2;         // powers of two: exact
+  const float m100 = 100.0f * inv_s2;                                          // -100 / sf as an integer
+  const float av_mul = a.wa.s_q1 / a.wa.s_q3;
+  const int c_ch = lane & 31, half = lane >> 5;
+  const int jb = half ? (N + 1) / 2 : 0, je = half ? N : (N + 1) / 2;
+  for (int i = 0; i < N; ++i) {
+    double acc = 0.0;
+#pragma unroll
+    for (int c4 = 0; c4 < WA_HD / 4; ++c4) {
+      const float4 qv = *reinterpret_cast<const float4*>(&sQ[wave][i * WA_HD + 4 * c4]);     // broadcast read
+      acc = __builtin_fma((double)qv.x, kd[4 * c4 + 0], acc);
+      acc = __builtin_fma((double)qv.y, kd[4 * c4 + 1], acc);
+      acc = __builtin_fma((double)qv.z, kd[4 * c4 + 2], acc);
+      acc = __builtin_fma((double)qv.w, kd[4 * c4 + 3], acc);
+    }
+    const float attn = (float)(acc * (double)a.wa.s_q1);                       // k*s1: exact scaling, then ONE rounding
+    const float a1 = __builtin_amdgcn_fmed3f(rintf(attn * inv_sa), -128.f, 127.f);          // qact_attn1
+    const int iy = i / ws, ix = i % ws;
+    const float bc = (float)sT[wave][(iy - jy + ws - 1) * (2 * ws - 1) + (ix - jx + ws - 1)];
+    const float a2 = __builtin_amdgcn_fmed3f(rintf((a1 * a.wa.s_attn + bc * a.wa.s_table) * inv_s2), -128.f, 127.f);   // qact2
+    const int regi = a.wa.region ? (int)a.wa.region[w * N + i] : 0;
+    const bool masked = regi != regj;
+    int xi = (int)a2;
+    int cmp = live ? (masked ? xi - (int)m100 : xi) : -2000000000;
+    int mx = cmp;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
+    int d = mx - cmp;
+    d = d > 256 ? 256 : d;
+    d = live ? d : 257;
+    long long S = lutE[d];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) S += __shfl_xor(S, o);
+    const float Sf = (float)S;
+    const float2 fr = lutFR[d];
+    const float r0 = Sf * fr.y;
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-fr.x, r0, Sf), fr.y, r0);
+    const float r2 = __builtin_fmaf(__builtin_fmaf(-fr.x, r1, Sf), fr.y, r1);
+    const float ratio = rintf(r2);                                             // round(sum / exp_int), exact quotient
+    int k = (int)((__float_as_uint(ratio) + 0x00400000u) >> 23) - 127;         // log_round
+    k = k > 16 ? 16 : k;
+    const float P = (k < 16 && live) ? __uint_as_float((unsigned)(127 - k) << 23) : 0.f;
+    sP[wave][lane] = P;
+    if (a.probs_k && live)
+      a.probs_k[((((long long)b * nW + w) * a.H + head) * N + i) * N + lane] = (int8_t)k;
+    // P . V with lane = channel; the two half waves take half of the keys each
+    float o = 0.f;
+    for (int jj = jb; jj < je; ++jj) o = __builtin_fmaf(sP[wave][jj], sV[wave][jj * WA_HD + c_ch], o);
+    o += __shfl_xor(o, 32);
+    if (half == 0) {
+      const int rowi = a.wa.win_index[w * N + i];
+      const float qv = __builtin_amdgcn_fmed3f(rintf(o * av_mul), -128.f, 127.f);           // qact3: (attn@v) = o*s_q1
+      a.out[((long long)b * a.T + rowi) * C + head * WA_HD + c_ch] = (int8_t)(int)qv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // module-level helpers
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fake_quant_f32(const float* __restrict__ x, long long n, const float* __restrict__ scale,
@@ -1444,6 +1565,13 @@ static int launch_attn_t(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((k_lis_attention<HD, NKB, true>), dim3(a.B * a.H), dim3(64 * g_attn_waves), smem, st, a);
   else
     hipLaunchKernelGGL((k_lis_attention<HD, NKB, false>), dim3(a.B * a.H), dim3(64 * g_attn_waves), smem, st, a);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int p2v_launch_window_attention(const WinAttnArgs& a, hipStream_t st) {
+  const int hgroups = (a.H + 3) / 4;
+  hipLaunchKernelGGL(k_window_attention, dim3((unsigned)(a.B * a.wa.n_windows * hgroups)), dim3(256), 0, st, a);
   CHECK_LAUNCH();
   return 0;
 }

@@ -38,6 +38,11 @@ class Attn(C.Structure):
                 ('c_int', _i)]
 
 
+class WinAttn(C.Structure):
+    _fields_ = [('s_q1', _f), ('qk_scale', _f), ('s_attn', _f), ('s_table', _f), ('s_q2', _f), ('s_q3', _f), ('x0_int', _i),
+                ('b_int', _i), ('c_int', _i), ('table_codes', _p), ('win_index', _p), ('region', _p), ('ws', _i), ('n_windows', _i)]
+
+
 class Epilogue(C.Structure):
     _fields_ = [('inv_s_out', _f), ('s_out', _f), ('s_mid', _p), ('s_res', _p), ('s_next', _p), ('residual', _p),
                 ('inv_s_pe', _f), ('pe_to_embed', _f), ('s_embed', _f), ('pos_deq', _p), ('patches', _i)]
@@ -88,6 +93,7 @@ def lib():
     L.p2v_gemm_i8.argtypes = [_i, _p, _i, _i, _i, _i, C.POINTER(Linear), C.POINTER(Epilogue), _p, _i, _p, _p]
     L.p2v_int_layernorm.argtypes = [_p, _ll, _i, _i, C.POINTER(Ln), _p, _ll, _p]
     L.p2v_lis_attention.argtypes = [_p, _i, _i, _i, _i, C.POINTER(Attn), _p, _p, _p]
+    L.p2v_window_attention.argtypes = [_p, _i, _i, _i, _i, C.POINTER(WinAttn), _p, _p, _p]
     L.p2v_fake_quant_f32.argtypes = [_p, _ll, _p, _i, _ll, _i, _i, _p, _p, _p]
     L.p2v_gelu_quant_f32.argtypes = [_p, _ll, _f, _p, _p, _i, _p]
     L.p2v_gelu_err_sweep.argtypes = [C.c_uint32, C.c_uint32, _p, _p]

@@ -194,6 +194,32 @@ int p2v_int_layernorm(const int8_t* x, long long row_stride, int rows, int C, co
 int p2v_lis_attention(const int8_t* qkv, int batch, int tokens, int heads, int head_dim, const p2v_attn* at,
                       int8_t* out, int8_t* probs_k, void* stream);
 
+/* Swin window attention core (WindowAttention.forward between qact1 and qact3, swin_quant.py:186-217; window partition /
+ * cyclic shift / reverse of SwinTransformerBlock.forward, swin_quant.py:366-391, folded into the addressing):
+ *   (q*scale) @ k^T -> qact_attn1 -> + qact_table(relative_position_bias_table)[index] -> qact2 -> (+ -100 mask) ->
+ *   QIntSoftmax(log-int, uint4, sf = qact2 scale) -> @ v -> qact3.
+ * q*scale rounds each element once in fp32 and the dot product over head_dim is exact (fp64), then rounded once. */
+typedef struct p2v_winattn {
+  float s_q1;        /* qact1 scale (pot)                                        */
+  float qk_scale;    /* head_dim^-0.5 (swin_quant.py:80)                         */
+  float s_attn;      /* qact_attn1 scale (pot)                                   */
+  float s_table;     /* qact_table scale (pot)                                   */
+  float s_q2;        /* qact2 scale (pot) = the softmax scaling factor           */
+  float s_q3;        /* qact3 scale (pot)                                        */
+  int32_t x0_int, b_int, c_int; /* I-BERT constants for sf = s_q2 (layers.py:334-351) */
+  const int8_t* table_codes;    /* dev [(2*ws-1)^2][heads] codes of qact_table(relative_position_bias_table) */
+  const int32_t* win_index;     /* dev [n_windows][ws*ws]: row (within the image) of token p of window w after shift+partition */
+  const int8_t* region;         /* dev [n_windows][ws*ws] shifted-window region ids, or NULL (no mask): pairs from different
+                                 * regions get -100 (swin_quant.py:325-349)                                                   */
+  int32_t ws, n_windows;
+} p2v_winattn;
+
+/* qkv int8 [batch][tokens_per_image][3*heads*head_dim] (qact1 codes, natural token order); out int8
+ * [batch][tokens_per_image][heads*head_dim] (qact3 codes, natural order).  head_dim must be 32.  probs_k optional:
+ * dev int8 [batch][n_windows][heads][N][N] log2 exponents (16 = zero). */
+int p2v_window_attention(const int8_t* qkv, int batch, int tokens_per_image, int heads, int head_dim,
+                         const p2v_winattn* wa, int8_t* out, int8_t* probs_k, void* stream);
+
 /* UniformQuantizer.forward on an fp32 tensor (uniform.py:50-127, base.py:42-45): fake-quant in place of
  * the eager round/clamp chain.  scale has `n_scale` entries (1 = layer-wise) applied along the channel
  * dimension: element i uses scale[(i / inner) % n_scale].  codes (optional) receives the int8 codes. */

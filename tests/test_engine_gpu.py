@@ -385,3 +385,104 @@ def test_custom_ops_match_c_abi(dva, oracle, micro):
     assert np.array_equal(out.cpu().numpy(), micro['g']['logits/q8'])
     with pytest.raises(RuntimeError):
         torch.ops.p2vit.forward(12345, xi, bits)
+
+
+# ------------------------------------------------------------------------------------------------
+# Swin window attention (A14): HIP kernel vs the oracle, which is pinned to the real reference by swin_winattn.npz
+# ------------------------------------------------------------------------------------------------
+def _winattn_call(E, qkv_codes, B, T, heads, c, table_codes, win_index, region, ws, nW, lis):
+    dev = dict(qkv=qkv_codes.to(torch.int8).contiguous().cuda(), tab=table_codes.to(torch.int8).contiguous().cuda(),
+               idx=win_index.to(torch.int32).contiguous().cuda(),
+               reg=None if region is None else region.to(torch.int8).contiguous().cuda())
+    wa = E.WinAttn(float(c['qact1']), float(np.float32(32 ** -0.5)), float(c['qact_attn1']), float(c['qact_table']),
+                   float(c['qact2']), float(c['qact3']), lis[0], lis[1], lis[2], E.ptr(dev['tab']), E.ptr(dev['idx']),
+                   E.ptr(dev['reg']) if dev['reg'] is not None else None, ws, nW)
+    C_ = heads * 32
+    out = torch.zeros(B * T, C_, dtype=torch.int8, device='cuda')
+    N = ws * ws
+    pk = torch.full((B, nW, heads, N, N), -1, dtype=torch.int8, device='cuda')
+    E.check(E.lib().p2v_window_attention(E.ptr(dev['qkv']), B, T, heads, 32, C.byref(wa), E.ptr(out), E.ptr(pk), E.stream_ptr()))
+    torch.cuda.synchronize()
+    return out.cpu(), pk.cpu()
+
+
+@pytest.mark.parametrize('tag', ['nomask', 'mask'])
+def test_window_attention_vs_reference_golden(dva, oracle, tag):
+    """the kernel reproduces the REAL reference's WindowAttention taps (qact1 codes in -> softmax exponents, qact3 codes out)."""
+    import swin_oracle as SO
+    from conftest import load_golden
+    E = dva.engine
+    g = load_golden('swin_winattn')
+    heads, ws, nW = 2, 7, 3
+    N = ws * ws
+    q1 = torch.from_numpy(g['taps/%s/qact1' % tag].astype(np.int64))          # [B_, N, 3C] qact1 codes from the reference
+    B_ = q1.shape[0]
+    c = {k: float(g['scale/' + k][0]) for k in ('qact1', 'qact_attn1', 'qact_table', 'qact2', 'qact3')}
+    tab = torch.from_numpy(g['taps/%s/qact_table' % tag].astype(np.int64))
+    lis = oracle.lis_consts(torch.tensor([c['qact2']]))
+    # reference mask -> region ids (the fixture's mask is region-structured: see oracle/gen_golden_swin.py)
+    region = None
+    if tag == 'mask':
+        m = torch.from_numpy(g['mask'])
+        region = torch.zeros(nW, N, dtype=torch.long)
+        for w in range(nW):
+            ids = {}
+            for p in range(N):
+                key = tuple((m[w, p] == 0).tolist())
+                region[w, p] = ids.setdefault(key, len(ids))
+        assert torch.equal((region.unsqueeze(1) != region.unsqueeze(2)).float() * -100.0, m)
+    idx = (torch.arange(nW).reshape(nW, 1) * N + torch.arange(N).reshape(1, N))
+    out, pk = _winattn_call(E, q1.reshape(B_ // nW, nW * N, -1), B_ // nW, nW * N, heads, c, tab, idx, region, ws, nW, lis)
+    want_k = torch.from_numpy(g['taps/%s/softmax_k' % tag].astype(np.int64)).reshape(B_ // nW, nW, heads, N, N)
+    assert torch.equal(pk.long(), want_k), int((pk.long() != want_k).sum())
+    want = torch.from_numpy(g['taps/%s/qact3' % tag].astype(np.int64)).reshape(-1, heads * 32)
+    assert torch.equal(out.long(), want), int((out.long() != want).sum())
+
+
+@pytest.mark.parametrize('heads,Hf,ws,shift,B', [(4, 14, 7, 3, 3), (8, 14, 7, 0, 2), (3, 8, 4, 2, 2), (16, 7, 7, 0, 5)])
+def test_window_attention_shifted_windows_vs_oracle(dva, oracle, heads, Hf, ws, shift, B):
+    """cyclic shift + partition + mask + scatter-back through the index/region tables, against the oracle."""
+    import swin_oracle as SO
+    E, S = dva.engine, dva.synth
+    C_ = heads * 32
+    T = Hf * Hf
+    N = ws * ws
+    qkv = _rand_codes(S, 9, 'wq%d' % heads, (B, T, 3 * C_), 25.0)
+    qkv[0, 0] = 127
+    tab = torch.clamp(torch.round(S.normal(9, 'wt%d' % heads, ((2 * ws - 1) ** 2, heads), 30.0)), -128, 127)
+    c = dict(qact1=2.0 ** -4, qact_attn1=2.0 ** -3, qact_table=2.0 ** -5, qact2=2.0 ** -4, qact3=2.0 ** -3)
+    idx = SO.window_index(Hf, Hf, ws, shift)
+    nW = idx.shape[0]
+    region = None
+    mask = None
+    if shift:
+        mask = SO.shifted_window_mask(Hf, Hf, ws, shift)
+        region = torch.zeros(nW, N, dtype=torch.long)
+        img = torch.zeros(Hf, Hf)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[hs, wsl] = cnt
+                cnt += 1
+        region = img.reshape(Hf // ws, ws, Hf // ws, ws).permute(0, 2, 1, 3).reshape(nW, N).long()
+    lis = oracle.lis_consts(torch.tensor([c['qact2']]))
+    out, pk = _winattn_call(E, qkv, B, T, heads, c, tab, idx, region, ws, nW, lis)
+    # oracle on the partitioned windows (scores/softmax/AV part of window_attention_quant, fed with qact1 codes directly)
+    xw = qkv[:, idx.reshape(-1)].reshape(B * nW, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    s1 = torch.tensor(c['qact1'])
+    qs = (xw[0] * s1) * torch.tensor(32 ** -0.5, dtype=torch.float32)
+    attn = (qs.double() @ (xw[1] * s1).double().transpose(-2, -1)).float()
+    a1 = SO.q8(attn, c['qact_attn1'])
+    bias = (tab * c['qact_table'])[SO.relative_position_index(ws).reshape(-1)].reshape(N, N, heads).permute(2, 0, 1)
+    a2 = SO.q8(a1 * c['qact_attn1'] + bias.unsqueeze(0), c['qact2'])
+    xi = a2
+    if mask is not None:
+        xi = (a2.reshape(B, nW, heads, N, N) + torch.round(mask / c['qact2']).unsqueeze(1).unsqueeze(0)).reshape(B * nW, heads, N, N)
+    k = oracle.lis_int(xi, torch.tensor([c['qact2']]))
+    o = (oracle.lis_probs(k) @ (xw[2] * s1)).transpose(1, 2).reshape(B, nW * N, C_)
+    q3 = SO.q8(o, c['qact3'])
+    want = torch.zeros(B, T, C_)
+    want[:, idx.reshape(-1)] = q3
+    assert torch.equal(pk.long().reshape(B * nW, heads, N, N), k.long()), int((pk.long().reshape(B * nW, heads, N, N) != k.long()).sum())
+    assert torch.equal(out.float().reshape(B, T, C_), want), int((out.float().reshape(B, T, C_) != want).sum())
+    assert (k < 16).any() and (k == 16).any()
