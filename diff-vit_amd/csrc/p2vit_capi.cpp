@@ -362,6 +362,20 @@ int p2v_lis_attention(const int8_t* qkv, int batch, int tokens, int heads, int h
   return launch_rc(p2v_launch_attention(a, head_dim, (hipStream_t)stream), "lis_attention");
 }
 
+int p2v_patch_merge_gather(const int8_t* x, int batch, int H, int W, int C, int8_t* out, void* stream) {
+  if (!x || !out) return fail(P2V_E_ARG, "p2v_patch_merge_gather: null argument");
+  if (batch <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return fail(P2V_E_SHAPE, "patch merge: H and W must be positive and even");
+  if (C <= 0 || C % 16) return fail(P2V_E_UNSUPPORTED, "patch merge: C must be a multiple of 16");
+  return launch_rc(p2v_launch_patch_merge_gather(x, batch, H, W, C, out, (hipStream_t)stream), "patch_merge_gather");
+}
+
+int p2v_avgpool_quant(const int8_t* x, int batch, int tokens, int C, float s_in, float inv_s_out, int8_t* out, void* stream) {
+  if (!x || !out) return fail(P2V_E_ARG, "p2v_avgpool_quant: null argument");
+  if (batch <= 0 || tokens <= 0 || tokens > 8192) return fail(P2V_E_SHAPE, "avgpool: bad shape");
+  if (C <= 0 || C % 4) return fail(P2V_E_UNSUPPORTED, "avgpool: C must be a multiple of 4");
+  return launch_rc(p2v_launch_avgpool_quant(x, batch, tokens, C, s_in, inv_s_out, out, (hipStream_t)stream), "avgpool_quant");
+}
+
 int p2v_window_attention(const int8_t* qkv, int batch, int tokens_per_image, int heads, int head_dim, const p2v_winattn* wa,
                          int8_t* out, int8_t* probs_k, void* stream) {
   if (!qkv || !wa || !out || !wa->table_codes || !wa->win_index) return fail(P2V_E_ARG, "p2v_window_attention: null argument");

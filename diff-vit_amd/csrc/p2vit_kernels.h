@@ -51,6 +51,8 @@ struct WinAttnArgs {
   int8_t* out;
   int8_t* probs_k;
 };
+int p2v_launch_patch_merge_gather(const int8_t* x, int B, int H, int W, int C, int8_t* out, hipStream_t st);
+int p2v_launch_avgpool_quant(const int8_t* x, int B, int T, int C, float s_in, float inv_s_out, int8_t* out, hipStream_t st);
 int p2v_launch_window_attention(const WinAttnArgs& a, hipStream_t st);
 
 int p2v_launch_patchify(const float* img, int B, int C, int H, int W, int P, float inv_s, int8_t* out, int k_pad, hipStream_t st);

@@ -1569,6 +1569,56 @@ static int launch_attn_t(const AttnArgs& a, hipStream_t st) {
   return 0;
 }
 
+// PatchMerging gather: 16-byte chunks, one thread each (C % 16 == 0)
+__global__ __launch_bounds__(256) void k_patch_merge_gather(const int8_t* __restrict__ x, int B, int H, int W, int C, int8_t* __restrict__ out) {
+  const int cpr = C / 16, H2 = H / 2, W2 = W / 2;
+  const long long total = (long long)B * H2 * W2 * 4 * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cpr);
+    long long r = i / cpr;
+    const int q = (int)(r % 4); r /= 4;               // x0..x3: q = 0 (dy0,dx0), 1 (dy1,dx0), 2 (dy0,dx1), 3 (dy1,dx1)
+    const int w2 = (int)(r % W2); r /= W2;
+    const int h2 = (int)(r % H2);
+    const int b = (int)(r / H2);
+    const int dy = q & 1, dx = q >> 1;
+    const uint4 v = *reinterpret_cast<const uint4*>(x + (((long long)b * H + 2 * h2 + dy) * W + 2 * w2 + dx) * C + ch * 16);
+    *reinterpret_cast<uint4*>(out + (((long long)b * H2 + h2) * W2 + w2) * 4 * C + q * C + ch * 16) = v;
+  }
+}
+
+// AdaptiveAvgPool1d over tokens + qact3: one thread per (image, 4 channels)
+__global__ __launch_bounds__(256) void k_avgpool_quant(const int8_t* __restrict__ x, int B, int T, int C, float s_in, float inv_s_out,
+                                                       int8_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C / 4;
+  if (i >= B * c4) return;
+  const int b = i / c4, c = (i % c4) * 4;
+  int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int t = 0; t < T; ++t) {
+    const unsigned w = *reinterpret_cast<const unsigned*>(x + ((long long)b * T + t) * C + c);
+    s0 += sx8(w, 0); s1 += sx8(w, 1); s2 += sx8(w, 2); s3 += sx8(w, 3);
+  }
+  const float Tf = (float)T;
+  *reinterpret_cast<unsigned*>(out + (long long)b * C + c) =
+      pack4_sat(rintf((((float)s0 * s_in) / Tf) * inv_s_out), rintf((((float)s1 * s_in) / Tf) * inv_s_out),
+                rintf((((float)s2 * s_in) / Tf) * inv_s_out), rintf((((float)s3 * s_in) / Tf) * inv_s_out));
+}
+
+int p2v_launch_patch_merge_gather(const int8_t* x, int B, int H, int W, int C, int8_t* out, hipStream_t st) {
+  const long long total = (long long)B * (H / 2) * (W / 2) * 4 * (C / 16);
+  int blocks = (int)((total + 255) / 256);
+  blocks = blocks > 256 * 32 ? 256 * 32 : (blocks < 1 ? 1 : blocks);
+  hipLaunchKernelGGL(k_patch_merge_gather, dim3(blocks), dim3(256), 0, st, x, B, H, W, C, out);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int p2v_launch_avgpool_quant(const int8_t* x, int B, int T, int C, float s_in, float inv_s_out, int8_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_avgpool_quant, dim3((B * (C / 4) + 255) / 256), dim3(256), 0, st, x, B, T, C, s_in, inv_s_out, out);
+  CHECK_LAUNCH();
+  return 0;
+}
+
 int p2v_launch_window_attention(const WinAttnArgs& a, hipStream_t st) {
   const int hgroups = (a.H + 3) / 4;
   hipLaunchKernelGGL(k_window_attention, dim3((unsigned)(a.B * a.wa.n_windows * hgroups)), dim3(256), 0, st, a);

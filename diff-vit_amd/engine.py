@@ -93,6 +93,8 @@ def lib():
     L.p2v_gemm_i8.argtypes = [_i, _p, _i, _i, _i, _i, C.POINTER(Linear), C.POINTER(Epilogue), _p, _i, _p, _p]
     L.p2v_int_layernorm.argtypes = [_p, _ll, _i, _i, C.POINTER(Ln), _p, _ll, _p]
     L.p2v_lis_attention.argtypes = [_p, _i, _i, _i, _i, C.POINTER(Attn), _p, _p, _p]
+    L.p2v_patch_merge_gather.argtypes = [_p, _i, _i, _i, _i, _p, _p]
+    L.p2v_avgpool_quant.argtypes = [_p, _i, _i, _i, _f, _f, _p, _p]
     L.p2v_window_attention.argtypes = [_p, _i, _i, _i, _i, C.POINTER(WinAttn), _p, _p, _p]
     L.p2v_fake_quant_f32.argtypes = [_p, _ll, _p, _i, _ll, _i, _i, _p, _p, _p]
     L.p2v_gelu_quant_f32.argtypes = [_p, _ll, _f, _p, _p, _i, _p]

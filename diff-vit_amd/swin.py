@@ -1,0 +1,351 @@
+"""Swin Transformer on the drop-in module surface (reference: models/swin_quant.py).
+
+Same class / attribute / state-dict names as the reference (``patch_embed.proj``, ``layers.i.blocks.j.attn.qkv`` ...,
+``relative_position_bias_table``, ``layers.i.downsample.reduction``), same state switches (``model_quant`` ...,
+swin_quant.py:762-788) and the same float/calibration graph.  The reference's Swin cannot run as shipped (its PatchEmbed and Mlp
+are called with the wrong arity and the bias-less ``PatchMerging.reduction`` cannot calibrate; SURVEY.md 8c caveat 3), so this
+module fixes exactly those three points and nothing else:
+  * ``PatchEmbed`` / ``Mlp`` take no FLOPs / bit_config arguments here (Mlp = fc1 -> GELU -> qact1 -> fc2 -> qact2, the FQ-ViT
+    block the Swin code was written against);
+  * the bias-less reduction calibrates with ``bias=None``;
+  * weights run at the width the calibration loop leaves selected, int8 (``forward(x, bits=4)`` selects the int4 scales).
+In quant state the whole forward is HIP kernels through the C ABI (``swin_plan.SwinPlan``); there is no CPU path.
+"""
+import torch
+import torch.nn as nn
+
+from .ptq import QAct, QConv2d, QIntLayerNorm, QIntSoftmax, QLinear
+from .vit import _qact, _qlinear
+
+__all__ = ['SwinTransformer', 'swin_micro_patch4_window7_56', 'swin_tiny_patch4_window7_224', 'swin_small_patch4_window7_224',
+           'swin_base_patch4_window7_224']
+
+
+def window_partition(x, ws):
+    B, H, W, C = x.shape
+    return x.view(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, ws, ws, C)
+
+
+def window_reverse(windows, ws, H, W):
+    B = int(windows.shape[0] / (H * W / ws / ws))
+    return windows.view(B, H // ws, W // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).contiguous().view(B, H, W, -1)
+
+
+def relative_position_index(ws):
+    coords = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing='ij'))
+    cf = torch.flatten(coords, 1)
+    rel = (cf[:, :, None] - cf[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def shifted_window_regions(H, W, ws, shift):
+    """[nW, ws*ws] region ids of the shifted-window mask (swin_quant.py:325-343); the mask is -100 where ids differ."""
+    img = torch.zeros(H, W, dtype=torch.long)
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[hs, wsl] = cnt
+            cnt += 1
+    return img.view(H // ws, ws, W // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+
+
+class WindowAttention(nn.Module):
+    """swin_quant.py:53-221"""
+
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, quant=False, calibrate=False, cfg=None):
+        super().__init__()
+        self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        ws = window_size[0]
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) * (2 * ws - 1), num_heads))
+        self.register_buffer('relative_position_index', relative_position_index(ws))
+        self.qkv = _qlinear(cfg, dim, dim * 3, quant, calibrate, bias=qkv_bias)
+        self.qact1 = _qact(cfg, quant, calibrate)
+        self.qact_attn1 = _qact(cfg, quant, calibrate)
+        self.qact_table = _qact(cfg, quant, calibrate)
+        self.qact2 = _qact(cfg, quant, calibrate)
+        self.log_int_softmax = QIntSoftmax(log_i_softmax=cfg.INT_SOFTMAX, quant=quant, calibrate=calibrate, bit_type=cfg.BIT_TYPE_S,
+                                           calibration_mode=cfg.CALIBRATION_MODE_S, observer_str=cfg.OBSERVER_S,
+                                           quantizer_str=cfg.QUANTIZER_S)
+        self.qact3 = _qact(cfg, quant, calibrate)
+        self.qact4 = _qact(cfg, quant, calibrate)
+        self.proj = _qlinear(cfg, dim, dim, quant, calibrate)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
+
+    def forward(self, x, mask=None):
+        B_, N, C = x.shape
+        x = self.qact1(self.qkv(x))
+        qkv = x.reshape(B_, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        attn = self.qact_attn1((q * self.scale) @ k.transpose(-2, -1))
+        table = self.qact_table(self.relative_position_bias_table)
+        bias = table[self.relative_position_index.view(-1)].view(N, N, -1).permute(2, 0, 1).contiguous()
+        attn = self.qact2(attn + bias.unsqueeze(0))
+        if mask is not None:
+            nW = mask.shape[0]
+            attn = (attn.view(B_ // nW, nW, self.num_heads, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, self.num_heads, N, N)
+        attn = self.log_int_softmax(attn, self.qact2.quantizer.scale)
+        x = (attn @ v).transpose(1, 2).reshape(B_, N, C)
+        return self.qact4(self.proj(self.qact3(x)))
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features, quant=False, calibrate=False, cfg=None):
+        super().__init__()
+        self.fc1 = _qlinear(cfg, in_features, hidden_features, quant, calibrate)
+        self.act = nn.GELU()
+        self.qact1 = _qact(cfg, quant, calibrate)
+        self.fc2 = _qlinear(cfg, hidden_features, in_features, quant, calibrate)
+        self.qact2 = _qact(cfg, quant, calibrate)
+
+    def forward(self, x):
+        return self.qact2(self.fc2(self.qact1(self.act(self.fc1(x)))))
+
+
+class SwinTransformerBlock(nn.Module):
+    """swin_quant.py:224-399"""
+
+    def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0, mlp_ratio=4.0, qkv_bias=True,
+                 norm_layer=QIntLayerNorm, quant=False, calibrate=False, cfg=None):
+        super().__init__()
+        self.dim, self.input_resolution, self.num_heads = dim, input_resolution, num_heads
+        self.window_size, self.shift_size = window_size, shift_size
+        if min(input_resolution) <= window_size:
+            self.shift_size, self.window_size = 0, min(input_resolution)
+        assert 0 <= self.shift_size < self.window_size, 'shift_size must in 0-window_size'
+        self.norm1 = norm_layer(dim)
+        self.qact1 = _qact(cfg, quant, calibrate)
+        self.attn = WindowAttention(dim, (self.window_size, self.window_size), num_heads, qkv_bias, quant, calibrate, cfg)
+        self.qact2 = _qact(cfg, quant, calibrate, ln=True)
+        self.norm2 = norm_layer(dim)
+        self.qact3 = _qact(cfg, quant, calibrate)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), quant, calibrate, cfg)
+        self.qact4 = _qact(cfg, quant, calibrate, ln=True)
+        mask = None
+        if self.shift_size > 0:
+            H, W = input_resolution
+            reg = shifted_window_regions(H, W, self.window_size, self.shift_size).float()
+            d = reg.unsqueeze(1) - reg.unsqueeze(2)
+            mask = d.masked_fill(d != 0, -100.0).masked_fill(d == 0, 0.0)
+        self.register_buffer('attn_mask', mask)
+
+    def forward(self, x, last_quantizer=None):
+        H, W = self.input_resolution
+        B, L, C = x.shape
+        assert L == H * W, 'input feature has wrong size'
+        shortcut = x
+        x = self.qact1(self.norm1(x, last_quantizer, self.qact1.quantizer)).view(B, H, W, C)
+        if self.shift_size > 0:
+            x = torch.roll(x, shifts=(-self.shift_size, -self.shift_size), dims=(1, 2))
+        xw = window_partition(x, self.window_size).view(-1, self.window_size * self.window_size, C)
+        aw = self.attn(xw, mask=self.attn_mask).view(-1, self.window_size, self.window_size, C)
+        x = window_reverse(aw, self.window_size, H, W)
+        if self.shift_size > 0:
+            x = torch.roll(x, shifts=(self.shift_size, self.shift_size), dims=(1, 2))
+        x = self.qact2(shortcut + x.view(B, H * W, C))
+        x = x + self.mlp(self.qact3(self.norm2(x, self.qact2.quantizer, self.qact3.quantizer)))
+        return self.qact4(x)
+
+
+class PatchMerging(nn.Module):
+    """swin_quant.py:402-470"""
+
+    def __init__(self, input_resolution, dim, norm_layer=QIntLayerNorm, quant=False, calibrate=False, cfg=None):
+        super().__init__()
+        self.input_resolution, self.dim = input_resolution, dim
+        self.norm = norm_layer(4 * dim)
+        self.qact1 = _qact(cfg, quant, calibrate)
+        self.reduction = _qlinear(cfg, 4 * dim, 2 * dim, quant, calibrate, bias=False)
+        self.qact2 = _qact(cfg, quant, calibrate, ln=True)
+
+    def forward(self, x, last_quantizer=None):
+        H, W = self.input_resolution
+        B, L, C = x.shape
+        assert L == H * W, 'input feature has wrong size'
+        assert H % 2 == 0 and W % 2 == 0, f'x size ({H}*{W}) are not even.'
+        x = x.view(B, H, W, C)
+        x = torch.cat([x[:, 0::2, 0::2, :], x[:, 1::2, 0::2, :], x[:, 0::2, 1::2, :], x[:, 1::2, 1::2, :]], -1).view(B, -1, 4 * C)
+        x = self.qact1(self.norm(x, last_quantizer, self.qact1.quantizer, None, 4))
+        return self.qact2(self.reduction(x))
+
+
+class BasicLayer(nn.Module):
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size, mlp_ratio=4.0, qkv_bias=True, norm_layer=QIntLayerNorm,
+                 downsample=None, quant=False, calibrate=False, cfg=None):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim, input_resolution, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio,
+                                 qkv_bias, norm_layer, quant, calibrate, cfg) for i in range(depth)])
+        self.downsample = downsample(input_resolution, dim, norm_layer, quant, calibrate, cfg) if downsample is not None else None
+
+    def forward(self, x, last_quantizer=None):
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, last_quantizer if i == 0 else self.blocks[i - 1].qact4.quantizer)
+        if self.downsample is not None:
+            x = self.downsample(x, self.blocks[-1].qact4.quantizer)
+        return x
+
+
+class PatchEmbed(nn.Module):
+    """layers_quant.py:355-492 with a norm layer (the Swin configuration)"""
+
+    def __init__(self, img_size, patch_size, in_chans, embed_dim, norm_layer, quant=False, calibrate=False, cfg=None):
+        super().__init__()
+        self.img_size, self.patch_size = (img_size, img_size), (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = QConv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, quant=quant, calibrate=calibrate,
+                            bit_type=cfg.BIT_TYPE_W, calibration_mode=cfg.CALIBRATION_MODE_W, observer_str=cfg.OBSERVER_W,
+                            quantizer_str=cfg.QUANTIZER_W)
+        self.qact_before_norm = _qact(cfg, quant, calibrate)
+        self.norm = norm_layer(embed_dim)
+        self.qact = _qact(cfg, quant, calibrate)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        assert H == self.img_size[0] and W == self.img_size[1], \
+            f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+        x = self.qact_before_norm(self.proj(x, None).flatten(2).transpose(1, 2))
+        return self.qact(self.norm(x, self.qact_before_norm.quantizer, self.qact.quantizer))
+
+
+class SwinTransformer(nn.Module):
+    """swin_quant.py:569-817"""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, num_classes=1000, embed_dim=96, depths=(2, 2, 6, 2),
+                 num_heads=(3, 6, 12, 24), window_size=7, mlp_ratio=4.0, qkv_bias=True, norm_layer=QIntLayerNorm, quant=False,
+                 calibrate=False, input_quant=True, cfg=None, **kwargs):
+        super().__init__()
+        self.arch = dict(img_size=img_size, patch_size=patch_size, embed_dim=embed_dim, depths=tuple(depths), num_heads=tuple(num_heads),
+                         window_size=window_size, mlp_ratio=mlp_ratio, num_classes=num_classes)
+        self.num_classes, self.num_layers, self.embed_dim = num_classes, len(depths), embed_dim
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.cfg, self.input_quant, self.in_chans = cfg, input_quant, in_chans
+        self.quant = quant
+        if input_quant:
+            self.qact_input = _qact(cfg, quant, calibrate)
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim, norm_layer, quant, calibrate, cfg)
+        self.patch_grid = self.patch_embed.grid_size
+        self.absolute_pos_embed = None
+        layers = []
+        for i in range(self.num_layers):
+            res = (self.patch_grid[0] // (2 ** i), self.patch_grid[1] // (2 ** i))
+            layers.append(BasicLayer(int(embed_dim * 2 ** i), res, depths[i], num_heads[i], window_size, mlp_ratio, qkv_bias, norm_layer,
+                                     PatchMerging if i < self.num_layers - 1 else None, quant, calibrate, cfg))
+        self.layers = nn.Sequential(*layers)
+        self.norm = norm_layer(self.num_features)
+        self.qact2 = _qact(cfg, quant, calibrate)
+        self.avgpool = nn.AdaptiveAvgPool1d(1)
+        self.qact3 = _qact(cfg, quant, calibrate)
+        self.head = _qlinear(cfg, self.num_features, num_classes, quant, calibrate)
+        self.act_out = _qact(cfg, quant, calibrate)
+        self.apply(self._init_weights)
+        self._plan = None
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # ---- state switches (swin_quant.py:762-788) ------------------------------------------------------------------------
+    def _q_modules(self):
+        return [m for m in self.modules() if type(m) in (QConv2d, QLinear, QAct, QIntSoftmax)]
+
+    def model_quant(self):
+        self.quant = True
+        for m in self._q_modules():
+            m.quant = True
+        if self.cfg.INT_NORM:
+            for m in self.modules():
+                if type(m) is QIntLayerNorm:
+                    m.mode = 'int'
+        self._plan = None
+
+    def model_dequant(self):
+        self.quant = False
+        for m in self._q_modules():
+            m.quant = False
+
+    def model_open_calibrate(self):
+        for m in self._q_modules():
+            m.calibrate = True
+        self._plan = None
+
+    def model_open_last_calibrate(self):
+        for m in self._q_modules():
+            m.last_calibrate = True
+
+    def model_close_calibrate(self):
+        for m in self._q_modules():
+            m.calibrate = False
+
+    def load_state_dict(self, *a, **k):
+        self._plan = None
+        return super().load_state_dict(*a, **k)
+
+    def _calibrating(self):
+        return any(m.calibrate for m in self._q_modules())
+
+    # ---- frozen state -------------------------------------------------------------------------------------------------
+    def export_calib(self):
+        """{module path: scale tensor} for every QAct, {module path: {bit type: scale}} for every QLinear / QConv2d."""
+        c = {}
+        for name, m in self.named_modules():
+            if type(m) is QAct and m.quantizer.scale is not None:
+                c[name] = m.quantizer.scale.detach().float().cpu().reshape(-1)
+            elif type(m) in (QLinear, QConv2d):
+                c[name] = {k: v.detach().float().cpu().reshape(-1) for k, v in m.quantizer.dic_scale.items()}
+        return c
+
+    def freeze(self, device=None, bits=8):
+        from .swin_plan import SwinPlan
+        if not self.input_quant:
+            raise NotImplementedError('the HIP engine fuses qact_input into the patch gather: input_quant=True models only')
+        if not (self.cfg.INT_NORM and self.cfg.INT_SOFTMAX):
+            raise NotImplementedError('the HIP engine implements the ptf=True, lis=True configuration')
+        dev = device or self.head.weight.device
+        self._plan = SwinPlan(self.arch, dict(self.state_dict()), self.export_calib(), device=dev, in_chans=self.in_chans, bits=bits)
+        return self._plan
+
+    # ---- forward -----------------------------------------------------------------------------------------------------
+    def forward_features(self, x):
+        if self.input_quant:
+            x = self.qact_input(x)
+        x = self.patch_embed(x)
+        for i, layer in enumerate(self.layers):
+            lq = self.patch_embed.qact.quantizer if i == 0 else self.layers[i - 1].downsample.qact2.quantizer
+            x = layer(x, lq)
+        x = self.qact2(self.norm(x, self.layers[-1].blocks[-1].qact4.quantizer, self.qact2.quantizer))
+        x = self.qact3(self.avgpool(x.transpose(1, 2)))
+        return torch.flatten(x, 1)
+
+    def forward(self, x, bits=8):
+        if self.quant and not self._calibrating():
+            # ---- THE HOT PATH: HIP kernels through the C ABI ------------------------------------------------------------------
+            if self._plan is None or self._plan.bits != bits:
+                self.freeze(x.device if x.is_cuda else None, bits=bits)
+            return self._plan.forward(x)
+        return self.act_out(self.head(self.forward_features(x)))
+
+
+def _factory(embed_dim, depths, num_heads, img_size=224):
+    def make(pretrained=False, quant=False, calibrate=False, cfg=None, **kwargs):
+        if pretrained:
+            raise RuntimeError('no network in this environment: load a local checkpoint with load_state_dict(...)')
+        kw = dict(patch_size=4, window_size=7, embed_dim=embed_dim, depths=depths, num_heads=num_heads, img_size=img_size)
+        kw.update(kwargs)
+        return SwinTransformer(norm_layer=QIntLayerNorm, quant=quant, calibrate=calibrate, input_quant=True, cfg=cfg, **kw)
+    return make
+
+
+swin_tiny_patch4_window7_224 = _factory(96, (2, 2, 6, 2), (3, 6, 12, 24))
+swin_small_patch4_window7_224 = _factory(96, (2, 2, 18, 2), (3, 6, 12, 24))
+swin_base_patch4_window7_224 = _factory(128, (2, 2, 18, 2), (4, 8, 16, 32))
+swin_micro_patch4_window7_56 = _factory(64, (2, 2), (2, 4), img_size=56)     # 14x14 -> 7x7 tokens: both shift/no-shift and one merge

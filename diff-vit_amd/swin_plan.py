@@ -1,0 +1,262 @@
+"""Frozen integer plan of a calibrated Swin model: int8 weight codes and per-channel requant constants on the GPU, and a forward
+that is a fixed sequence of HIP kernels called through the C ABI (``p2v_quantize_patchify``, ``p2v_gemm_i8``,
+``p2v_int_layernorm``, ``p2v_window_attention``, ``p2v_patch_merge_gather``, ``p2v_avgpool_quant``).  Window partition, cyclic
+shift and their inverses are index tables consumed by the attention kernel; nothing runs on the CPU and nothing falls back.
+
+Call order = swin_quant.py (forward_features :790-811, SwinTransformerBlock.forward :351-399, PatchMerging.forward :438-461).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import engine as E
+from .swin import relative_position_index, shifted_window_regions  # noqa: F401
+
+
+def _pad128(n):
+    return (n + 127) // 128 * 128
+
+
+def _lis_consts(sf):
+    """x0_int, b_int, c_int of the I-BERT polynomial in fp32 (layers.py:334-351)."""
+    sf = torch.tensor(float(sf), dtype=torch.float32)
+    x0 = torch.floor(-0.6931 / sf)
+    b = torch.floor((0.96963238 / 0.35815147) / sf)
+    c = torch.floor((1. / 0.35815147) / sf ** 2)
+    return int(x0), int(b), int(c)
+
+
+def _window_index(H, W, ws, shift):
+    hh = (torch.arange(H) + shift) % H
+    ww = (torch.arange(W) + shift) % W
+    grid = hh[:, None] * W + ww[None, :]
+    return grid.reshape(H // ws, ws, W // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+
+
+class SwinPlan:
+    def __init__(self, arch, state_dict, calib, device='cuda', in_chans=3, bits=8):
+        self.arch, self.device, self.in_chans, self.bits = dict(arch), torch.device(device), in_chans, bits
+        if self.device.type != 'cuda':
+            raise RuntimeError('SwinPlan needs a GPU device: the quantized forward has no CPU path')
+        E.lib()
+        self._keep = []
+        self.W = {k: v.detach().float().cpu() for k, v in state_dict.items() if v.dtype == torch.float32}
+        self.c = calib
+        self._build()
+
+    # ---- helpers -------------------------------------------------------------------------------------------------------
+    def _dev(self, t, dtype=torch.float32):
+        t = t.to(dtype).contiguous().to(self.device)
+        self._keep.append(t)
+        return t
+
+    def _vec(self, v, n):
+        """per-channel fp32 vector of length n, padded to a multiple of 128 (whole tiles are staged)."""
+        v = torch.as_tensor(v, dtype=torch.float32).reshape(-1)
+        if v.numel() == 1:
+            v = v.expand(n)
+        out = torch.ones(_pad128(n))
+        out[:n] = v
+        return self._dev(out)
+
+    def _pot(self, name):
+        s = float(self.c[name].reshape(-1)[0])
+        m, _ = np.frexp(s)
+        if self.c[name].numel() != 1 or m != 0.5:
+            raise NotImplementedError('%s: the engine needs a power-of-two layer-wise scale, got %r' % (name, self.c[name][:4]))
+        return s
+
+    def _linear(self, name, s_x, bias=True, k_pad=None):
+        """int8-stored weight codes [n_pad][k_pad], colscale = s_x * s_w, bias."""
+        bt = 'int%d' % self.bits
+        w = self.W[name + '.weight']
+        w2 = w.reshape(w.shape[0], -1)
+        N, K = w2.shape
+        s_w = self.c[name][bt].reshape(-1)
+        lo, hi = (-128, 127) if self.bits == 8 else (-8, 7)
+        codes = torch.clamp(torch.round(w2 / s_w.reshape(-1, 1)), lo, hi)
+        kp = k_pad or K
+        wp = torch.zeros(_pad128(N), kp, dtype=torch.int8)
+        wp[:N, :K] = codes.to(torch.int8)
+        cs = torch.zeros(_pad128(N))
+        cs[:N] = (torch.tensor(float(s_x)) * s_w.expand(N)).float()
+        b = torch.zeros(_pad128(N))
+        if bias:
+            b[:N] = self.W[name + '.bias']
+        d = dict(w=self._dev(wp, torch.int8), cs=self._dev(cs), b=self._dev(b), N=N, K=kp)
+        d['lin'] = E.Linear(E.ptr(d['w']), E.ptr(d['cs']), E.ptr(d['b']))
+        return d
+
+    def _ln(self, prefix, s_in_vec, s_out, C_):
+        """QIntLayerNorm 'int' constants: mask = round(in_scale / min), inv_out = 1 / out_scale; the following QAct has the LN's
+        own output scale, so post_mul = 1."""
+        s_in_vec = torch.as_tensor(s_in_vec, dtype=torch.float32).reshape(-1)
+        if s_in_vec.numel() == 1:
+            s_in_vec = s_in_vec.expand(C_)
+        s1 = s_in_vec.min()
+        t = [self._dev(torch.round(s_in_vec / s1)), self._dev(self.W[prefix + '.weight']), self._dev(self.W[prefix + '.bias']),
+             self._dev(torch.full((C_,), 1.0 / float(s_out))), self._dev(torch.ones(C_))]
+        return E.Ln(float(s1), *[E.ptr(x) for x in t])
+
+    # ---- plan ----------------------------------------------------------------------------------------------------------
+    def _build(self):
+        a, c = self.arch, self.c
+        P, D0, ws = a['patch_size'], a['embed_dim'], a['window_size']
+        g = a['img_size'] // P
+        self.g = g
+        self.s_in = self._pot('qact_input')
+        kpatch = self.in_chans * P * P
+        self.k_patch = (kpatch + 63) // 64 * 64
+        self.pe = self._linear('patch_embed.proj', self.s_in, k_pad=self.k_patch)
+        self.s_pe_b = self._pot('patch_embed.qact_before_norm')
+        s_pe = self._pot('patch_embed.qact')
+        self.pe_ln = self._ln('patch_embed.norm', torch.tensor([self.s_pe_b]), s_pe, D0)
+        s_res = torch.full((D0,), s_pe)
+        self.stages = []
+        H = g
+        for li, depth in enumerate(a['depths']):
+            Cc = D0 * 2 ** li
+            heads = a['num_heads'][li]
+            if Cc // heads != 32:
+                raise NotImplementedError('window attention kernel: head_dim must be 32 (got %d)' % (Cc // heads))
+            wsz = min(ws, H)
+            blocks = []
+            for bi in range(depth):
+                p = 'layers.%d.blocks.%d.' % (li, bi)
+                shift = 0 if (bi % 2 == 0 or H <= ws) else ws // 2
+                s1 = self._pot(p + 'qact1')
+                b = dict(C=Cc, heads=heads, H=H, ws=wsz, shift=shift)
+                b['ln1'] = self._ln(p + 'norm1', s_res, s1, Cc)
+                s_q1 = self._pot(p + 'attn.qact1')
+                b['qkv'] = self._linear(p + 'attn.qkv', s1)
+                b['inv_s_qkv'] = 1.0 / s_q1
+                s_q2 = self._pot(p + 'attn.qact2')
+                s_q3 = self._pot(p + 'attn.qact3')
+                tab = torch.clamp(torch.round(self.W[p + 'attn.relative_position_bias_table'] / self._pot(p + 'attn.qact_table')), -128, 127)
+                idx = _window_index(H, H, wsz, shift)
+                reg = shifted_window_regions(H, H, wsz, shift) if shift else None
+                x0, bb, cc = _lis_consts(s_q2)
+                b['tab'], b['idx'] = self._dev(tab, torch.int8), self._dev(idx, torch.int32)
+                b['reg'] = self._dev(reg, torch.int8) if reg is not None else None
+                b['wa'] = E.WinAttn(s_q1, float(np.float32(32 ** -0.5)), self._pot(p + 'attn.qact_attn1'), self._pot(p + 'attn.qact_table'),
+                                    s_q2, s_q3, x0, bb, cc, E.ptr(b['tab']), E.ptr(b['idx']),
+                                    E.ptr(b['reg']) if b['reg'] is not None else None, wsz, idx.shape[0])
+                b['proj'] = self._linear(p + 'attn.proj', s_q3)
+                s_b2 = c[p + 'qact2'].reshape(-1)
+                b['proj_epi'] = self._resid_epi(self._pot(p + 'attn.qact4'), s_res, s_b2, Cc)
+                s3 = self._pot(p + 'qact3')
+                b['ln2'] = self._ln(p + 'norm2', s_b2, s3, Cc)
+                b['fc1'] = self._linear(p + 'mlp.fc1', s3)
+                s_m1 = self._pot(p + 'mlp.qact1')
+                b['inv_s_fc1'] = 1.0 / s_m1
+                b['fc2'] = self._linear(p + 'mlp.fc2', s_m1)
+                s_b4 = c[p + 'qact4'].reshape(-1)
+                b['fc2_epi'] = self._resid_epi(self._pot(p + 'mlp.qact2'), s_b2, s_b4, Cc)
+                s_res = s_b4.clone()
+                blocks.append(b)
+            st = dict(blocks=blocks, C=Cc, H=H, merge=None)
+            if li < len(a['depths']) - 1:
+                p = 'layers.%d.downsample.' % li
+                sd1 = self._pot(p + 'qact1')
+                sd2 = c[p + 'qact2'].reshape(-1)
+                red = self._linear(p + 'reduction', sd1, bias=False)
+                # single PTF requant through the RESID epilogue: s_mid = s_next and an all-zero residual make it
+                # Q(Q(y; s) * s; s) = Q(y; s)   (|code * eps| << 0.5)
+                st['merge'] = dict(ln=self._ln(p + 'norm', s_res.repeat(4), sd1, 4 * Cc), red=red,
+                                   epi=self._resid_epi(sd2, torch.ones(2 * Cc), sd2, 2 * Cc))
+                s_res = sd2.clone()
+                H //= 2
+            self.stages.append(st)
+        Cl = D0 * 2 ** (len(a['depths']) - 1)
+        self.C_last, self.H_last = Cl, H
+        self.s_f = self._pot('qact2')
+        self.fin_ln = self._ln('norm', s_res, self.s_f, Cl)
+        self.s_pool = self._pot('qact3')
+        self.head = self._linear('head', self.s_pool)
+        self.s_out = self._pot('act_out')
+
+    def _resid_epi(self, s_mid, s_res, s_next, n):
+        e = E.Epilogue()
+        t = [self._vec(s_mid, n), self._vec(s_res, n), self._vec(s_next, n)]
+        e.s_mid, e.s_res, e.s_next = [C.cast(E.ptr(x), C.c_void_p) for x in t]
+        return e
+
+    # ---- forward -------------------------------------------------------------------------------------------------------
+    def _gemm(self, kind, x, lin, epi, out_dtype=torch.int8, out_codes=None):
+        M, K = x.shape
+        N = lin['N']
+        out = torch.empty(M, N, dtype=out_dtype, device=self.device)
+        E.check(E.lib().p2v_gemm_i8(kind, E.ptr(x), K, M, K, N, C.byref(lin['lin']), C.byref(epi), E.ptr(out), N,
+                                    E.ptr(out_codes) if out_codes is not None else None, E.stream_ptr()))
+        return out
+
+    def _layernorm(self, x, ln):
+        rows, Cc = x.shape
+        out = torch.empty_like(x)
+        E.check(E.lib().p2v_int_layernorm(E.ptr(x), Cc, rows, Cc, C.byref(ln), E.ptr(out), Cc, E.stream_ptr()))
+        return out
+
+    def forward(self, images, taps=None):
+        """images fp32 [B, in_chans, S, S] on the plan's device -> logits fp32 [B, classes] (act_out grid)."""
+        images = images.contiguous().float()
+        if images.device != self.device:
+            raise RuntimeError('images must live on %s' % self.device)
+        L = E.lib()
+        a = self.arch
+        B, P, g = images.shape[0], a['patch_size'], self.g
+        if tuple(images.shape[1:]) != (self.in_chans, a['img_size'], a['img_size']):
+            raise AssertionError("Input image size (%d*%d) doesn't match model (%d*%d)." % (images.shape[2], images.shape[3], a['img_size'], a['img_size']))
+        st = E.stream_ptr()
+
+        def tap(name, t):
+            if taps is not None:
+                taps[name] = t.clone()
+        patches = torch.zeros(B * g * g, self.k_patch, dtype=torch.int8, device=self.device)
+        E.check(L.p2v_quantize_patchify(E.ptr(images), B, self.in_chans, a['img_size'], a['img_size'], P, 1.0 / self.s_in, E.ptr(patches),
+                                        self.k_patch, st))
+        epi = E.Epilogue()
+        epi.inv_s_out = 1.0 / self.s_pe_b
+        x = self._layernorm(self._gemm(E.EPI_REQUANT, patches, self.pe, epi), self.pe_ln)
+        tap('patch_embed.qact', x)
+        zero_res = None
+        for li, stg in enumerate(self.stages):
+            T = stg['H'] * stg['H']
+            for bi, b in enumerate(stg['blocks']):
+                p = 'layers.%d.blocks.%d.' % (li, bi)
+                ln = self._layernorm(x, b['ln1'])
+                tap(p + 'qact1', ln)
+                epi = E.Epilogue()
+                epi.inv_s_out = b['inv_s_qkv']
+                qkv = self._gemm(E.EPI_REQUANT, ln, b['qkv'], epi)
+                att = torch.empty(B * T, b['C'], dtype=torch.int8, device=self.device)
+                E.check(L.p2v_window_attention(E.ptr(qkv), B, T, b['heads'], 32, C.byref(b['wa']), E.ptr(att), None, st))
+                b['proj_epi'].residual = C.cast(E.ptr(x), C.c_void_p)
+                x2 = self._gemm(E.EPI_RESID, att, b['proj'], b['proj_epi'])
+                tap(p + 'qact2', x2)
+                ln = self._layernorm(x2, b['ln2'])
+                epi = E.Epilogue()
+                epi.inv_s_out = b['inv_s_fc1']
+                hid = self._gemm(E.EPI_GELU, ln, b['fc1'], epi)
+                b['fc2_epi'].residual = C.cast(E.ptr(x2), C.c_void_p)
+                x = self._gemm(E.EPI_RESID, hid, b['fc2'], b['fc2_epi'])
+                tap(p + 'qact4', x)
+            if stg['merge'] is not None:
+                m = stg['merge']
+                H = stg['H']
+                gathered = torch.empty(B * (H // 2) * (H // 2), 4 * stg['C'], dtype=torch.int8, device=self.device)
+                E.check(L.p2v_patch_merge_gather(E.ptr(x), B, H, H, stg['C'], E.ptr(gathered), st))
+                ln = self._layernorm(gathered, m['ln'])
+                zero_res = torch.zeros(ln.shape[0], 2 * stg['C'], dtype=torch.int8, device=self.device)
+                m['epi'].residual = C.cast(E.ptr(zero_res), C.c_void_p)
+                x = self._gemm(E.EPI_RESID, ln, m['red'], m['epi'])
+                tap('layers.%d.downsample.qact2' % li, x)
+        fin = self._layernorm(x, self.fin_ln)
+        tap('qact2', fin)
+        pooled = torch.empty(B, self.C_last, dtype=torch.int8, device=self.device)
+        E.check(L.p2v_avgpool_quant(E.ptr(fin), B, self.H_last * self.H_last, self.C_last, self.s_f, 1.0 / self.s_pool, E.ptr(pooled), st))
+        tap('qact3', pooled)
+        # the GEMM needs K % 64 == 0 rows of 16-byte alignment: C_last is a multiple of 64 for every Swin variant here
+        epi = E.Epilogue()
+        epi.inv_s_out, epi.s_out = 1.0 / self.s_out, self.s_out
+        return self._gemm(E.EPI_HEAD, pooled, self.head, epi, out_dtype=torch.float32)

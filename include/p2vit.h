@@ -220,6 +220,14 @@ typedef struct p2v_winattn {
 int p2v_window_attention(const int8_t* qkv, int batch, int tokens_per_image, int heads, int head_dim,
                          const p2v_winattn* wa, int8_t* out, int8_t* probs_k, void* stream);
 
+/* PatchMerging.forward gather (swin_quant.py:446-459): x int8 [batch][H*W][C] -> out int8 [batch][(H/2)*(W/2)][4*C] in the
+ * reference's channel order x0 (even row, even col), x1 (odd row, even col), x2 (even row, odd col), x3 (odd, odd). */
+int p2v_patch_merge_gather(const int8_t* x, int batch, int H, int W, int C, int8_t* out, void* stream);
+
+/* SwinTransformer.forward_features tail (swin_quant.py:806-808): AdaptiveAvgPool1d over the tokens of the fake-quantised
+ * qact2 output (codes * s_in, power-of-two s_in: the sum is exact), then qact3: out[b][c] = clamp(round((sum*s_in / tokens) * inv_s_out)). */
+int p2v_avgpool_quant(const int8_t* x, int batch, int tokens, int C, float s_in, float inv_s_out, int8_t* out, void* stream);
+
 /* UniformQuantizer.forward on an fp32 tensor (uniform.py:50-127, base.py:42-45): fake-quant in place of
  * the eager round/clamp chain.  scale has `n_scale` entries (1 = layer-wise) applied along the channel
  * dimension: element i uses scale[(i / inner) % n_scale].  codes (optional) receives the int8 codes. */

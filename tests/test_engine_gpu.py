@@ -486,3 +486,50 @@ def test_window_attention_shifted_windows_vs_oracle(dva, oracle, heads, Hf, ws, 
     assert torch.equal(pk.long().reshape(B * nW, heads, N, N), k.long()), int((pk.long().reshape(B * nW, heads, N, N) != k.long()).sum())
     assert torch.equal(out.float().reshape(B, T, C_), want), int((out.float().reshape(B, T, C_) != want).sum())
     assert (k < 16).any() and (k == 16).any()
+
+
+def _micro_swin(dva, seed=5, n=4):
+    from diff_vit_amd import swin
+    S = dva.synth
+    cfg = dva.Config(True, True, 'minmax')
+    m = swin.swin_micro_patch4_window7_56(cfg=cfg, num_classes=10).eval()
+    sd = m.state_dict()
+    for k, v in sd.items():
+        if v.dtype != torch.float32 or 'index' in k or 'mask' in k:
+            continue
+        if k.endswith(('norm.weight', 'norm1.weight', 'norm2.weight')):
+            sd[k] = S.uniform(seed, k, tuple(v.shape), 0.6, 1.4)
+        elif 'norm' in k and k.endswith('bias'):
+            sd[k] = S.normal(seed, k, tuple(v.shape), 0.1)
+        elif k.endswith('bias'):
+            sd[k] = S.normal(seed, k, tuple(v.shape), 0.05)
+        elif 'table' in k:
+            sd[k] = S.normal(seed, k, tuple(v.shape), 0.5)
+        else:
+            sd[k] = S.normal(seed, k, tuple(v.shape), 0.08)
+    m.load_state_dict(sd)
+    return m, S.images(seed, n, 56)
+
+
+@pytest.mark.parametrize('bits', [8, 4])
+def test_swin_micro_engine_vs_oracle(dva, oracle, bits):
+    """whole-model Swin (2 stages, shifted windows, one PatchMerging) through the drop-in surface: HIP plan == OracleSwin on every
+    residual-stream tap and on the logits; OracleSwin == the module surface's own torch fake-quant graph (CPU test)."""
+    import swin_oracle as SO
+    m, x = _micro_swin(dva)
+    with torch.no_grad():
+        m.model_open_calibrate(); m.model_open_last_calibrate(); m(x[:2]); m.model_close_calibrate()
+        m.model_quant()
+        m.cuda()
+        out = m(x.cuda(), bits=bits)
+        taps_g = {}
+        m._plan.forward(x.cuda(), taps=taps_g)
+        torch.cuda.synchronize()
+        taps_o = {}
+        ref = SO.OracleSwin(m.arch, {k: v.cpu() for k, v in m.state_dict().items()}).quant_forward(x, m.export_calib(), bits, taps_o)
+    for name, t in taps_g.items():
+        want = taps_o[name].reshape(t.shape)
+        assert torch.equal(t.cpu().int(), want.int()), (name, int((t.cpu().int() != want.int()).sum()), t.numel())
+    assert len(taps_g) >= 12
+    assert torch.equal(out.cpu(), ref), float((out.cpu() - ref).abs().max())
+    assert len(set(ref.argmax(1).tolist())) > 1

@@ -1,5 +1,6 @@
 """CPU: the Swin-operator oracle against vectors produced by the real reference (tests/golden/swin_winattn.npz)."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden
@@ -58,3 +59,39 @@ def test_window_index_and_mask_match_torch_ops():
     # gather order of PatchMerging
     y = SO.patch_merge_gather(x.reshape(B, H * W, C), H, W)
     assert torch.equal(y[0, 0], torch.cat([x[0, 0, 0], x[0, 1, 0], x[0, 0, 1], x[0, 1, 1]]))
+
+
+def test_swin_model_oracle_equals_module_fake_quant_graph(synth):
+    """OracleSwin (functional restatement) == the Swin module surface executed op by op in torch fake-quant mode on CPU: the
+    surface is composed of the reference-pinned QAct/QLinear/QIntLayerNorm/QIntSoftmax classes in swin_quant.py's call order."""
+    import diff_vit_amd as dva
+    from diff_vit_amd import swin
+    import swin_oracle as SO
+    cfg = dva.Config(True, True, 'minmax')
+    m = swin.swin_micro_patch4_window7_56(cfg=cfg, num_classes=10).eval()
+    sd = m.state_dict()
+    for k, v in sd.items():
+        if v.dtype != torch.float32 or 'index' in k or 'mask' in k:
+            continue
+        if k.endswith(('norm.weight', 'norm1.weight', 'norm2.weight')):
+            sd[k] = synth.uniform(5, k, tuple(v.shape), 0.6, 1.4)
+        elif 'norm' in k and k.endswith('bias'):
+            sd[k] = synth.normal(5, k, tuple(v.shape), 0.1)
+        elif k.endswith('bias'):
+            sd[k] = synth.normal(5, k, tuple(v.shape), 0.05)
+        elif 'table' in k:
+            sd[k] = synth.normal(5, k, tuple(v.shape), 0.5)
+        else:
+            sd[k] = synth.normal(5, k, tuple(v.shape), 0.08)
+    m.load_state_dict(sd)
+    x = synth.images(5, 3, 56)
+    with torch.no_grad():
+        fp = m(x)
+        m.model_open_calibrate(); m.model_open_last_calibrate(); m(x[:2]); m.model_close_calibrate()
+        m.model_quant()
+        y_mod = m.act_out(m.head(m.forward_features(x)))           # the op-by-op fake-quant graph (not the product path)
+        y_or = SO.OracleSwin(m.arch, m.state_dict()).quant_forward(x, m.export_calib(), 8)
+    assert fp.shape == (3, 10)
+    assert torch.equal(y_mod, y_or)
+    with pytest.raises(RuntimeError):                              # the product path has no CPU fallback
+        m(x)
