@@ -7,7 +7,11 @@ from .plan import FrozenPlan  # noqa: F401
 from .ptq import BIT_TYPE_DICT, QAct, QConv2d, QIntLayerNorm, QIntSoftmax, QLinear  # noqa: F401
 from .vit import (VisionTransformer, deit_base_patch16_224, deit_small_patch16_224, deit_tiny_patch16_224,  # noqa: F401
                   vit_base_patch16_224, vit_large_patch16_224)
+from .swin import (SwinTransformer, swin_base_patch4_window7_224, swin_small_patch4_window7_224,  # noqa: F401
+                   swin_tiny_patch4_window7_224)
+from .swin_plan import SwinPlan  # noqa: F401
 
 __all__ = ['BIT_TYPE_DICT', 'QAct', 'QConv2d', 'QIntLayerNorm', 'QIntSoftmax', 'QLinear', 'Config', 'VisionTransformer',
            'deit_tiny_patch16_224', 'deit_small_patch16_224', 'deit_base_patch16_224', 'vit_base_patch16_224',
-           'vit_large_patch16_224', 'FrozenPlan']
+           'vit_large_patch16_224', 'FrozenPlan', 'SwinTransformer', 'swin_tiny_patch4_window7_224',
+           'swin_small_patch4_window7_224', 'swin_base_patch4_window7_224', 'SwinPlan']

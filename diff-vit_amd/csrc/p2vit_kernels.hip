@@ -873,16 +873,17 @@ __device__ __forceinline__ float ln_elem_generic(float xq, float g, float bta, f
 // 8 significant bits of A, i.e.  sign*M*2^-N == A with the low 16 mantissa bits cleared =: T;  and
 // rint(((sM*xq + Bv) rounded) * 2^-N) == rint(fma(T, xq, Bv*2^-N))  because T*xq is exact (8 x 11 bits) and scaling by
 // 2^-N commutes with the rounding.  Bit-identical to the generic chain (tests drive both through P2V_LN_GENERIC=1).
-template <int NCH>
+// LANES = 32: one row per half wave (C <= 1024);  LANES = 64: one row per wave (PatchMerging rows of up to 2048 channels)
+template <int NCH, int LANES>
 __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
   // per-channel constants are folded once per workgroup, shared through LDS, then held in registers (re-reading them from
   // LDS per row frees 46 VGPRs but measured 10 % slower: the kernel is bound by VALU issue, not by occupancy)
-  __shared__ __attribute__((aligned(16))) float sG[NCH * 128], sB[NCH * 128], sP[NCH * 128];
-  __shared__ __attribute__((aligned(16))) int sM[NCH * 128];
-  const int tid = threadIdx.x, l32 = tid & 31, hw = tid >> 5;
+  __shared__ __attribute__((aligned(16))) float sG[NCH * LANES * 4], sB[NCH * LANES * 4], sP[NCH * LANES * 4];
+  __shared__ __attribute__((aligned(16))) int sM[NCH * LANES * 4];
+  const int tid = threadIdx.x, l32 = tid & (LANES - 1), hw = tid / LANES;   // l32: lane within the row group
   int potf = a.force_generic ? 0 : 1;
-  if (tid < NCH * 32) {   // one thread per 4 channels: fold, test, and publish
-    const int c = tid * 4;
+  for (int t4 = tid; t4 < NCH * LANES; t4 += 256) {   // one thread per 4 channels: fold, test, and publish
+    const int c = t4 * 4;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f), b = g, io = make_float4(1.f, 1.f, 1.f, 1.f), pmv = g, mk = g;
     if (c < a.C) {
       g = *reinterpret_cast<const float4*>(a.ln.gamma + c);
@@ -918,7 +919,7 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
   float gmin = 3.0e38f, gmax = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = (l32 + 32 * i) * 4;
+    const int c = (l32 + LANES * i) * 4;
     on[i] = c < a.C;
     const float4 gv = *reinterpret_cast<const float4*>(sG + c);
     gm[i] = gv;
@@ -937,6 +938,10 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
 #undef LN_MM
     lo = min(lo, __builtin_amdgcn_ds_swizzle(lo, 0x401F));
     hi = max(hi, __builtin_amdgcn_ds_swizzle(hi, 0x401F));
+    if (LANES == 64) {
+      lo = min(lo, __shfl_xor(lo, 32));
+      hi = max(hi, __shfl_xor(hi, 32));
+    }
     gmin = __uint_as_float((unsigned)lo);
     gmax = __uint_as_float((unsigned)hi);
   }
@@ -944,13 +949,13 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
   const float Cf = (float)a.C;
   const float s1oC = s1 / Cf;
   const int LN_ROWS = a.rows_per_half;
-  const long long row0 = ((long long)blockIdx.x * 8 + hw) * LN_ROWS;
+  const long long row0 = ((long long)blockIdx.x * (256 / LANES) + hw) * LN_ROWS;
   // Row r+1 is requested at the top of the iteration of row r and first touched just before the stores of row r.  The two
   // empty asm statements pin that placement: left alone, hipcc sinks the loads of a loop-carried value to the loop end,
   // behind the stores, and waits vmcnt(0) there - two exposed memory round trips per row (measured: 3 us per row).
   int colofs[NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) colofs[i] = on[i] ? (l32 + 32 * i) * 4 : 0;     // clamped: loads are unconditional
+  for (int i = 0; i < NCH; ++i) colofs[i] = on[i] ? (l32 + LANES * i) * 4 : 0;     // clamped: loads are unconditional
   const long long last_row = a.rows - 1;
   unsigned wnext[NCH];
 #pragma unroll
@@ -973,7 +978,7 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
     }
     float xq[NCH][4];
     int S1 = 0;
-    int S2 = 0;                                   // C * (128*8)^2 < 2^31 for C < 2048: exact in 32 bits
+    unsigned S2 = 0;                              // C * (128*8)^2 <= 2^31 for C <= 2048: exact in 32 unsigned bits
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const unsigned w = wcur[i];
@@ -983,11 +988,15 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
         const int v = __mul24(sx8(w, j), m4[j]);           // x_q * in_scale_mask  (layers.py:269-273); w == 0 past C
         xq[i][j] = (float)v;
         S1 += v;
-        S2 += __mul24(v, v);
+        S2 += (unsigned)__mul24(v, v);
       }
     }
     S1 = half_wave_sum(S1);
-    S2 = half_wave_sum(S2);
+    S2 = (unsigned)half_wave_sum((int)S2);        // two's-complement adds: the unsigned total is exact
+    if (LANES == 64) {
+      S1 += __shfl_xor(S1, 32);
+      S2 += (unsigned)__shfl_xor((int)S2, 32);
+    }
     const float S1f = (float)S1, S2f = (float)S2;
     const float mean = (S1f / Cf) * s1;                                  // x_q.mean(-1) * in_scale1
     const float stdv = s1oC * sqrtf(Cf * S2f - S1f * S1f);               // layers.py:276-277
@@ -1025,7 +1034,7 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
     } else {
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int cc = on[i] ? (l32 + 32 * i) * 4 : 0;
+        const int cc = on[i] ? (l32 + LANES * i) * 4 : 0;
         const float4 gv = *reinterpret_cast<const float4*>(a.ln.gamma + cc), bv = *reinterpret_cast<const float4*>(a.ln.beta + cc);
         const float4 iv = *reinterpret_cast<const float4*>(a.ln.inv_out + cc), pv = *reinterpret_cast<const float4*>(a.ln.post_mul + cc);
         const float g4[4] = {gv.x, gv.y, gv.z, gv.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
@@ -1041,7 +1050,7 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
     int8_t* dst = a.out + row * a.out_stride;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
-      if (on[i]) *reinterpret_cast<unsigned*>(dst + (l32 + 32 * i) * 4) = outw[i];
+      if (on[i]) *reinterpret_cast<unsigned*>(dst + (l32 + LANES * i) * 4) = outw[i];
   }
 }
 
@@ -1541,17 +1550,27 @@ int p2v_launch_layernorm(const LnArgs& a_, hipStream_t st) {
   a.force_generic = g_ln_generic;
   a.rows_per_half = g_ln_rows;
   const int LN_ROWS = g_ln_rows;
-  const int nch = (a.C + 127) / 128;
-  const int rows_per_block = 8 * LN_ROWS;
+  const bool wide = a.C > 1024;                 // one row per wave (64 lanes x 4 channels x up to 8 groups = 2048 channels)
+  const int nch = wide ? (a.C + 255) / 256 : (a.C + 127) / 128;
+  const int rows_per_block = (wide ? 4 : 8) * LN_ROWS;
   dim3 grid((unsigned)((a.rows + rows_per_block - 1) / rows_per_block)), block(256);
-  switch (nch) {
-    case 1: hipLaunchKernelGGL(k_int_layernorm<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(k_int_layernorm<2>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(k_int_layernorm<3>, grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(k_int_layernorm<4>, grid, block, 0, st, a); break;
-    case 6: hipLaunchKernelGGL(k_int_layernorm<6>, grid, block, 0, st, a); break;
-    case 8: hipLaunchKernelGGL(k_int_layernorm<8>, grid, block, 0, st, a); break;
-    default: return -1;
+  if (wide) {
+    switch (nch) {
+      case 5: hipLaunchKernelGGL((k_int_layernorm<5, 64>), grid, block, 0, st, a); break;
+      case 6: hipLaunchKernelGGL((k_int_layernorm<6, 64>), grid, block, 0, st, a); break;
+      case 8: hipLaunchKernelGGL((k_int_layernorm<8, 64>), grid, block, 0, st, a); break;
+      default: return -1;
+    }
+  } else {
+    switch (nch) {
+      case 1: hipLaunchKernelGGL((k_int_layernorm<1, 32>), grid, block, 0, st, a); break;
+      case 2: hipLaunchKernelGGL((k_int_layernorm<2, 32>), grid, block, 0, st, a); break;
+      case 3: hipLaunchKernelGGL((k_int_layernorm<3, 32>), grid, block, 0, st, a); break;
+      case 4: hipLaunchKernelGGL((k_int_layernorm<4, 32>), grid, block, 0, st, a); break;
+      case 6: hipLaunchKernelGGL((k_int_layernorm<6, 32>), grid, block, 0, st, a); break;
+      case 8: hipLaunchKernelGGL((k_int_layernorm<8, 32>), grid, block, 0, st, a); break;
+      default: return -1;
+    }
   }
   CHECK_LAUNCH();
   return 0;

@@ -46,14 +46,28 @@ def build_parser():
 
 
 def str2model(name):
-    """test_quant.py:56-68 (the Swin entries need the windowed-attention path: not built yet)."""
+    """test_quant.py:56-68"""
+    from . import swin
     d = {'deit_tiny': vit.deit_tiny_patch16_224, 'deit_small': vit.deit_small_patch16_224,
          'deit_base': vit.deit_base_patch16_224, 'vit_base': vit.vit_base_patch16_224,
-         'vit_large': vit.vit_large_patch16_224}
-    if name.startswith('swin'):
-        raise NotImplementedError('%s: the Swin graph is stale in the reference itself (no runnable oracle); not built' % name)
+         'vit_large': vit.vit_large_patch16_224, 'swin_tiny': swin.swin_tiny_patch4_window7_224,
+         'swin_small': swin.swin_small_patch4_window7_224, 'swin_base': swin.swin_base_patch4_window7_224}
     print('Model: %s' % name)
     return d[name]
+
+
+def _is_swin(model):
+    from .swin import SwinTransformer
+    return isinstance(model, SwinTransformer)
+
+
+def _forward(model, data, bit_config=None):
+    """``model(data, bit_config, plot)`` -> (output, FLOPs, distance).  The reference's Swin returns the logits alone and takes
+    no bit_config (swin_quant.py:813-817): a uniform bit_config selects its weight width, FLOPs/distance stay empty."""
+    if _is_swin(model):
+        bits = int(bit_config[0]) if bit_config else 8
+        return model(data, bits=bits), [], []
+    return model(data, bit_config, False)
 
 
 def seed(seed=0):
@@ -98,7 +112,7 @@ def calibrate_model(model, calibrate_data):
     model.model_open_calibrate()
     with torch.no_grad():
         model.model_open_last_calibrate()
-        output, FLOPs, global_distance = model(calibrate_data, plot=False)
+        output, FLOPs, global_distance = _forward(model, calibrate_data)
     model.model_close_calibrate()
     model.model_quant()
     return output, FLOPs, global_distance
@@ -133,7 +147,7 @@ def validate(args, val_loader, model, criterion, device, bit_config=None):
         target = target.to(device)
         t0 = time.time()
         with torch.no_grad():
-            output, FLOPs, distance = model(data, bit_config, False)
+            output, FLOPs, distance = _forward(model, data, bit_config)
         if data.is_cuda:
             torch.cuda.synchronize()
         fwd += time.time() - t0
@@ -166,19 +180,22 @@ def main(argv=None):
     cfg = Config(args.ptf, args.lis, args.quant_method)
     model = str2model(args.model)(pretrained=False, cfg=cfg)
     arch = model.arch
-    model.load_state_dict(synth.vit_state_dict(arch, args.seed), strict=False)
+    if _is_swin(model):
+        model.load_state_dict(synth.swin_state_dict(model.state_dict(), args.seed))
+    else:
+        model.load_state_dict(synth.vit_state_dict(arch, args.seed), strict=False)
     model = model.to(device).eval()
     # labels: the float model's own top-1 ("agreement with fp32"), the metric BASELINE.json names besides images/sec
     loader = SyntheticLoader(args.n_val, args.val_batchsize, arch['img_size'], arch['num_classes'], args.seed, device)
     with torch.no_grad():
-        tgt = torch.cat([model(d)[0].argmax(1).cpu() for d, _ in loader])
+        tgt = torch.cat([_forward(model, d)[0].argmax(1).cpu() for d, _ in loader])
     loader = SyntheticLoader(args.n_val, args.val_batchsize, arch['img_size'], arch['num_classes'], args.seed, device, tgt)
     criterion = nn.CrossEntropyLoss().to(device)
     bit_config = None
     if args.quant:
         print('Calibrating with Gaussian noise...')
         calibrate_model(model, synth.images(args.seed + 1, args.calib_batchsize, arch['img_size']).to(device))
-        bit_config = [args.bits] * (4 * arch['depth'] + 2)
+        bit_config = [args.bits] * ((4 * arch['depth'] + 2) if 'depth' in arch else 1)
         print(bit_config)
     return validate(args, loader, model, criterion, device, bit_config)
 

@@ -125,3 +125,26 @@ def vit_state_dict(arch: dict, seed: int = 0, in_chans: int = 3) -> dict:
     sd['norm.bias'] = normal(seed, 'norm.bias', (D,), 0.05)
     lin('head', arch['num_classes'], D, 0.06)
     return sd
+
+
+def swin_state_dict(template, seed):
+    """deterministic non-degenerate fill of a Swin state_dict (same keys/shapes as ``template``, e.g. ``model.state_dict()``):
+    LN gamma in U(0.6, 1.4), LN beta N(0, 0.1), biases N(0, 0.05), relative-position tables N(0, 0.5), matrices N(0, 0.6/sqrt(fan_in)),
+    the patch-embed conv N(0, 0.08).  Integer buffers (relative_position_index, attn_mask) are kept."""
+    import torch
+    out = {}
+    for k, v in template.items():
+        shp = tuple(v.shape)
+        if v.dtype != torch.float32 or 'index' in k or 'mask' in k:
+            out[k] = v
+        elif k.endswith(('norm.weight', 'norm1.weight', 'norm2.weight')):
+            out[k] = uniform(seed, k, shp, 0.6, 1.4)
+        elif 'norm' in k and k.endswith('bias'):
+            out[k] = normal(seed, k, shp, 0.1)
+        elif k.endswith('bias'):
+            out[k] = normal(seed, k, shp, 0.05)
+        elif 'table' in k:
+            out[k] = normal(seed, k, shp, 0.5)
+        else:
+            out[k] = normal(seed, k, shp, 0.6 / (shp[-1] ** 0.5) if v.dim() == 2 else 0.08)
+    return out

@@ -69,21 +69,7 @@ def test_swin_model_oracle_equals_module_fake_quant_graph(synth):
     import swin_oracle as SO
     cfg = dva.Config(True, True, 'minmax')
     m = swin.swin_micro_patch4_window7_56(cfg=cfg, num_classes=10).eval()
-    sd = m.state_dict()
-    for k, v in sd.items():
-        if v.dtype != torch.float32 or 'index' in k or 'mask' in k:
-            continue
-        if k.endswith(('norm.weight', 'norm1.weight', 'norm2.weight')):
-            sd[k] = synth.uniform(5, k, tuple(v.shape), 0.6, 1.4)
-        elif 'norm' in k and k.endswith('bias'):
-            sd[k] = synth.normal(5, k, tuple(v.shape), 0.1)
-        elif k.endswith('bias'):
-            sd[k] = synth.normal(5, k, tuple(v.shape), 0.05)
-        elif 'table' in k:
-            sd[k] = synth.normal(5, k, tuple(v.shape), 0.5)
-        else:
-            sd[k] = synth.normal(5, k, tuple(v.shape), 0.08)
-    m.load_state_dict(sd)
+    m.load_state_dict(synth.swin_state_dict(m.state_dict(), 5))
     x = synth.images(5, 3, 56)
     with torch.no_grad():
         fp = m(x)
