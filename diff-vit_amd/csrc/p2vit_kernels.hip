@@ -1252,24 +1252,30 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // K4: Swin window attention core (swin_quant.py:186-217, 366-391), head_dim 32, windows of ws*ws <= 64 tokens.
-//   One wave per (image, window, head); lane j is key/value token j of the window.  The reference multiplies the dequantised
-//   q by head_dim^-0.5 (not a power of two at head_dim 32) BEFORE the dot product, so the scores are sums of products of
-//   arbitrary fp32 values and 8-bit codes: the lane keeps its key as 32 doubles and accumulates v_fma_f64 (products have
-//   <= 32 significant bits, sums of 32 of them < 2^53: exact), then rounds once to fp32 - the canonical reading of the fp32
-//   matmul.  Window partition, cyclic shift and their inverses are a row-index table; the shifted-window mask is a region-id
-//   table (different regions -> -100, which after the clamp at 32*x0 is table entry 256; padding lanes use the zero entry 257).
-//   P.V runs with lane = channel (two half waves split the keys), exact in fp32 (sum P <= 1.5, values multiples of 2^-15).
+//   One wave per (image, window, head), four heads per workgroup; structure of k_lis_attention (S^T = K.Q^T on
+//   v_mfma_i32_16x16x64_i8, a score row on 4 lanes, exp_int table, exact int64 sum, P.V on v_mfma_f32_16x16x32_bf16).
+//   The reference multiplies the dequantised q by head_dim^-0.5 (not a power of two at head_dim 32) BEFORE the dot product:
+//   v_c = RN32(code_c * sigma), sigma = s_q1 * scale.  The rounding error of that product is a small integer number of
+//   units u = ulp(sigma):  v_c = code_c*sigma + eta_c*u with |eta_c| <= 64, eta_c = fma(code_c, sigma, -v_c)/u exactly.  So
+//       sum_c v_c k_c  =  sigma * (sum_c code_c k_c)  +  u * (sum_c eta_c k_c)
+//   is two int8 dot products: the K operand is duplicated into both halves of the 64-deep MFMA and the Q operand holds the
+//   codes in the lower half for the first product and the eta plane in the upper half for the second.  The two integers are
+//   combined in fp64 (exact: < 2^53) and rounded once to fp32 - the canonical reading of the reference's fp32 matmul.
+//   Window partition, cyclic shift and their inverses are a row-index table; the shifted-window mask is a region-id table
+//   (different regions -> -100, i.e. the clamp entry 256 of the exp table after max subtraction; padding keys use the zero
+//   entry 257); the relative-position index is linear in the token coordinates: lin_i - lin_j + const.
 // ---------------------------------------------------------------------------------------------------
 #define WA_HD 32
-#define WA_MAXN 64
-__global__ __launch_bounds__(256) void k_window_attention(WinAttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float sQ[4][WA_MAXN * WA_HD];     // RN32((q*s1)*scale)
-  __shared__ __attribute__((aligned(16))) float sV[4][WA_MAXN * WA_HD];     // v codes
-  __shared__ float sP[4][WA_MAXN];
-  __shared__ int8_t sT[4][232];                                              // bias-table column of the head ((2*8-1)^2 = 225 max)
+#define WA_KEYS 64
+__global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
+  constexpr int VSTRIDE = WA_KEYS + 4;                                         // bf16 elements
+  __shared__ __attribute__((aligned(16))) int8_t sK[4][WA_KEYS * WA_HD];
+  __shared__ __attribute__((aligned(16))) unsigned short sVt[4][WA_HD * VSTRIDE];
+  __shared__ int8_t sT[4][232];                                               // bias-table column of the head ((2*8-1)^2 = 225 max)
+  __shared__ unsigned short sMeta[WA_KEYS + 16];                               // per token: lin (y*(2ws-1)+x) | region << 10
   __shared__ long long lutE[258];
   __shared__ float2 lutFR[258];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int ws = a.wa.ws, N = ws * ws, nW = a.wa.n_windows;
   const int hgroups = (a.H + 3) >> 2;
   const int blk = blockIdx.x;
@@ -1291,82 +1297,154 @@ __global__ __launch_bounds__(256) void k_window_attention(WinAttnArgs a) {
     lutE[t] = e;
     lutFR[t] = make_float2(ef, (float)(1.0 / (double)ef));
   }
+  if (tid < WA_KEYS + 16) {
+    const int t = tid < N ? tid : 0;
+    const int reg = (a.wa.region && tid < N) ? (int)a.wa.region[w * N + t] : 0;
+    sMeta[tid] = (unsigned short)(((t / ws) * (2 * ws - 1) + (t % ws)) | (reg << 10));
+  }
   __syncthreads();
   if (head >= a.H) return;
   const int tsz = (2 * ws - 1) * (2 * ws - 1);
   for (int t = lane; t < tsz; t += 64) sT[wave][t] = a.wa.table_codes[t * a.H + head];
-  const bool live = lane < N;
-  const int j = live ? lane : N - 1;
-  const int rowj = a.wa.win_index[w * N + j];
-  const int8_t* base = a.qkv + ((long long)b * a.T + rowj) * 3 * C + head * WA_HD;
-  const uint4 q0 = *reinterpret_cast<const uint4*>(base), q1 = *reinterpret_cast<const uint4*>(base + 16);
-  const uint4 k0 = *reinterpret_cast<const uint4*>(base + C), k1 = *reinterpret_cast<const uint4*>(base + C + 16);
-  const uint4 v0 = *reinterpret_cast<const uint4*>(base + 2 * C), v1 = *reinterpret_cast<const uint4*>(base + 2 * C + 16);
-  const unsigned qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-  const unsigned kw[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-  const unsigned vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-  double kd[WA_HD];
-#pragma unroll
-  for (int c = 0; c < WA_HD; ++c) {
-    kd[c] = (double)sx8(kw[c >> 2], c & 3);
-    sQ[wave][lane * WA_HD + c] = ((float)sx8(qw[c >> 2], c & 3) * a.wa.s_q1) * a.wa.qk_scale;   // one rounding (s_q1 is 2^e)
-    sV[wave][lane * WA_HD + c] = (float)sx8(vw[c >> 2], c & 3);
-  }
-  const int regj = a.wa.region ? (int)a.wa.region[w * N + j] : 0;
-  const int jy = j / ws, jx = j % ws;
-  const float inv_sa = 1.0f / a.wa.s_attn, inv_s2 = 1.0f / a.wa.s_q2;         // powers of two: exact
-  const float m100 = 100.0f * inv_s2;                                          // -100 / sf as an integer
-  const float av_mul = a.wa.s_q1 / a.wa.s_q3;
-  const int c_ch = lane & 31, half = lane >> 5;
-  const int jb = half ? (N + 1) / 2 : 0, je = half ? N : (N + 1) / 2;
-  for (int i = 0; i < N; ++i) {
-    double acc = 0.0;
-#pragma unroll
-    for (int c4 = 0; c4 < WA_HD / 4; ++c4) {
-      const float4 qv = *reinterpret_cast<const float4*>(&sQ[wave][i * WA_HD + 4 * c4]);     // broadcast read
-      acc = __builtin_fma((double)qv.x, kd[4 * c4 + 0], acc);
-      acc = __builtin_fma((double)qv.y, kd[4 * c4 + 1], acc);
-      acc = __builtin_fma((double)qv.z, kd[4 * c4 + 2], acc);
-      acc = __builtin_fma((double)qv.w, kd[4 * c4 + 3], acc);
+  // stage K rows (int8) and V^T (bf16) of the window's tokens; rows >= N are zero
+  {
+    const bool live = lane < N;
+    const int rowj = a.wa.win_index[w * N + (live ? lane : 0)];
+    const int8_t* base = a.qkv + ((long long)b * a.T + rowj) * 3 * C + head * WA_HD;
+    uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0, v0 = k0, v1 = k0;
+    if (live) {
+      k0 = *reinterpret_cast<const uint4*>(base + C);
+      k1 = *reinterpret_cast<const uint4*>(base + C + 16);
+      v0 = *reinterpret_cast<const uint4*>(base + 2 * C);
+      v1 = *reinterpret_cast<const uint4*>(base + 2 * C + 16);
     }
-    const float attn = (float)(acc * (double)a.wa.s_q1);                       // k*s1: exact scaling, then ONE rounding
-    const float a1 = __builtin_amdgcn_fmed3f(rintf(attn * inv_sa), -128.f, 127.f);          // qact_attn1
-    const int iy = i / ws, ix = i % ws;
-    const float bc = (float)sT[wave][(iy - jy + ws - 1) * (2 * ws - 1) + (ix - jx + ws - 1)];
-    const float a2 = __builtin_amdgcn_fmed3f(rintf((a1 * a.wa.s_attn + bc * a.wa.s_table) * inv_s2), -128.f, 127.f);   // qact2
-    const int regi = a.wa.region ? (int)a.wa.region[w * N + i] : 0;
-    const bool masked = regi != regj;
-    int xi = (int)a2;
-    int cmp = live ? (masked ? xi - (int)m100 : xi) : -2000000000;
-    int mx = cmp;
+    *reinterpret_cast<uint4*>(&sK[wave][lane * WA_HD]) = k0;
+    *reinterpret_cast<uint4*>(&sK[wave][lane * WA_HD + 16]) = k1;
+    const unsigned vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
-    int d = mx - cmp;
-    d = d > 256 ? 256 : d;
-    d = live ? d : 257;
-    long long S = lutE[d];
+    for (int c = 0; c < WA_HD; ++c) {
+      const float f = (float)sx8(vw[c >> 2], c & 3);
+      sVt[wave][c * VSTRIDE + lane] = (unsigned short)(__float_as_uint(f) >> 16);   // exact bf16
+    }
+  }
+  const float sigma = a.wa.s_q1 * a.wa.qk_scale;                               // exact (s_q1 = 2^e)
+  const float inv_u = __uint_as_float((unsigned)(254 - (int)(__float_as_uint(sigma) >> 23) + 23) << 23);   // 1 / ulp(sigma)
+  const double sig_d = (double)sigma * (double)a.wa.s_q1;                      // * s_q1 of the keys: exact scaling
+  const double u_d = (1.0 / (double)inv_u) * (double)a.wa.s_q1;
+  const float inv_sa = 1.0f / a.wa.s_attn, inv_s2 = 1.0f / a.wa.s_q2;          // powers of two: exact
+  const int m100 = (int)(100.0f * inv_s2);                                     // 100 / sf as an integer
+  const float av_mul = a.wa.s_q1 / a.wa.s_q3;
+  const int c0 = (ws - 1) * (2 * ws - 1) + (ws - 1);
+  const int nqb = (N + 15) >> 4;
+  for (int qb = 0; qb < nqb; ++qb) {
+    const int qi = qb * 16 + l15;
+    const int qr = qi < N ? qi : N - 1;
+    const int rowq = a.wa.win_index[w * N + qr];
+    const v4i qc = *reinterpret_cast<const v4i*>(a.qkv + ((long long)b * a.T + rowq) * 3 * C + head * WA_HD + (g & 1) * 16);
+    v4i qeta;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) S += __shfl_xor(S, o);
+    for (int d4 = 0; d4 < 4; ++d4) {
+      unsigned pk = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float cf = (float)sx8((unsigned)qc[d4], e);
+        const float v = cf * sigma;                                             // RN32(code * sigma)
+        const int eta = (int)(__builtin_fmaf(cf, sigma, -v) * -inv_u);          // (v - code*sigma) / u, an integer in [-64, 64]
+        pk |= ((unsigned)eta & 255u) << (8 * e);
+      }
+      qeta[d4] = (int)pk;
+    }
+    const v4i fq1 = g < 2 ? qc : (v4i){0, 0, 0, 0};
+    const v4i fq2 = g < 2 ? (v4i){0, 0, 0, 0} : qeta;
+    v4i s1[4], s2[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const v4i fk = *reinterpret_cast<const v4i*>(&sK[wave][(kb * 16 + l15) * WA_HD + (g & 1) * 16]);
+      s1[kb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq1, (v4i){0, 0, 0, 0}, 0, 0, 0);
+      s2[kb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq2, (v4i){0, 0, 0, 0}, 0, 0, 0);
+    }
+    const unsigned mi = sMeta[qr];
+    const int lin_i = (int)(mi & 1023u) + c0, reg_i = (int)(mi >> 10);
+    int mx = -2000000000;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = kb * 16 + 4 * g + r;
+        const double e = __builtin_fma(sig_d, (double)s1[kb][r], (double)s2[kb][r] * u_d);      // exact
+        const float attn = (float)e;                                                           // ONE rounding
+        const float a1 = __builtin_amdgcn_fmed3f(rintf(attn * inv_sa), -128.f, 127.f);         // qact_attn1
+        const unsigned mj = sMeta[j];
+        const float bc = (float)sT[wave][lin_i - (int)(mj & 1023u)];
+        const float a2 = __builtin_amdgcn_fmed3f(rintf((a1 * a.wa.s_attn + bc * a.wa.s_table) * inv_s2), -128.f, 127.f);   // qact2
+        int xi = (int)a2 - (((int)(mj >> 10) != reg_i) ? m100 : 0);
+        xi = j < N ? xi : -2000000000;
+        s1[kb][r] = xi;
+        mx = xi > mx ? xi : mx;
+      }
+    }
+    {
+      int o = __shfl_xor(mx, 16);
+      mx = o > mx ? o : mx;
+      o = __shfl_xor(mx, 32);
+      mx = o > mx ? o : mx;
+    }
+    long long S = 0;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = kb * 16 + 4 * g + r;
+        int d = mx - s1[kb][r];
+        d = d > 256 ? 256 : d;
+        d = j < N ? d : 257;
+        s1[kb][r] = d;
+        S += lutE[d];
+      }
+    S += __shfl_xor(S, 16);
+    S += __shfl_xor(S, 32);
     const float Sf = (float)S;
-    const float2 fr = lutFR[d];
-    const float r0 = Sf * fr.y;
-    const float r1 = __builtin_fmaf(__builtin_fmaf(-fr.x, r0, Sf), fr.y, r0);
-    const float r2 = __builtin_fmaf(__builtin_fmaf(-fr.x, r1, Sf), fr.y, r1);
-    const float ratio = rintf(r2);                                             // round(sum / exp_int), exact quotient
-    int k = (int)((__float_as_uint(ratio) + 0x00400000u) >> 23) - 127;         // log_round
-    k = k > 16 ? 16 : k;
-    const float P = (k < 16 && live) ? __uint_as_float((unsigned)(127 - k) << 23) : 0.f;
-    sP[wave][lane] = P;
-    if (a.probs_k && live)
-      a.probs_k[((((long long)b * nW + w) * a.H + head) * N + i) * N + lane] = (int8_t)k;
-    // P . V with lane = channel; the two half waves take half of the keys each
-    float o = 0.f;
-    for (int jj = jb; jj < je; ++jj) o = __builtin_fmaf(sP[wave][jj], sV[wave][jj * WA_HD + c_ch], o);
-    o += __shfl_xor(o, 32);
-    if (half == 0) {
-      const int rowi = a.wa.win_index[w * N + i];
-      const float qv = __builtin_amdgcn_fmed3f(rintf(o * av_mul), -128.f, 127.f);           // qact3: (attn@v) = o*s_q1
-      a.out[((long long)b * a.T + rowi) * C + head * WA_HD + c_ch] = (int8_t)(int)qv;
+    v4f o[2] = {(v4f){0.f, 0.f, 0.f, 0.f}, (v4f){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      unsigned pk[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        unsigned hw2[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int jj = 2 * e2 + e;
+          const int kb = 2 * p + (jj >> 2), r = jj & 3;
+          const float2 fr = lutFR[s1[kb][r]];
+          const float r0 = Sf * fr.y;
+          const float r1 = __builtin_fmaf(__builtin_fmaf(-fr.x, r0, Sf), fr.y, r0);
+          const float r2 = __builtin_fmaf(__builtin_fmaf(-fr.x, r1, Sf), fr.y, r1);
+          const float ratio = rintf(r2);
+          int k = (int)((__float_as_uint(ratio) + 0x00400000u) >> 23) - 127;
+          k = k > 16 ? 16 : k;
+          hw2[e] = (k < 16 && s1[kb][r] != 257) ? (unsigned)(127 - k) << 7 : 0u;
+          if (a.probs_k && qi < N && kb * 16 + 4 * g + r < N)
+            a.probs_k[((((long long)b * nW + w) * a.H + head) * N + qi) * N + kb * 16 + 4 * g + r] = (int8_t)k;
+        }
+        pk[e2] = hw2[0] | (hw2[1] << 16);
+      }
+      v4i pb = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+      const v8bf fb = __builtin_bit_cast(v8bf, pb);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const unsigned short* vp = &sVt[wave][(dt * 16 + l15) * VSTRIDE + p * 32 + 4 * g];
+        const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
+        v4i va = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, va), fb, o[dt], 0, 0, 0);
+      }
+    }
+    if (qi < N) {
+      int8_t* dst = a.out + ((long long)b * a.T + rowq) * C + head * WA_HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        *reinterpret_cast<unsigned*>(dst + dt * 16) =
+            pack4_sat(rintf(o[dt][0] * av_mul), rintf(o[dt][1] * av_mul), rintf(o[dt][2] * av_mul), rintf(o[dt][3] * av_mul));
     }
   }
 }
