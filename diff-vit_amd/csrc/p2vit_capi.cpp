@@ -389,6 +389,9 @@ int p2v_window_attention(const int8_t* qkv, int batch, int tokens_per_image, int
     int ex;
     if (!(s > 0.f) || frexpf(s, &ex) != 0.5f) return fail(P2V_E_UNSUPPORTED, "window attention: activation scales must be powers of two");
   }
+  if (wa->qkv_stride % 16 || wa->out_stride % 4 || (wa->qkv_stride && wa->qkv_stride < 3 * heads * head_dim) ||
+      (wa->out_stride && wa->out_stride < heads * head_dim))
+    return fail(P2V_E_SHAPE, "window attention: row strides must cover a row and be 16 / 4 byte aligned");
   if (wa->s_q2 > 1.0f) return fail(P2V_E_UNSUPPORTED, "window attention: qact2 scale above 1 (the -100 mask would not be an integer)");
   WinAttnArgs a{qkv, batch, tokens_per_image, heads, *wa, out, probs_k};
   return launch_rc(p2v_launch_window_attention(a, (hipStream_t)stream), "window_attention");

@@ -1282,6 +1282,7 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
   const int hg = blk % hgroups, w = (blk / hgroups) % nW, b = blk / (hgroups * nW);
   const int head = hg * 4 + wave;
   const int C = a.H * WA_HD;
+  const long long ldq = a.wa.qkv_stride ? a.wa.qkv_stride : 3 * C, ldo = a.wa.out_stride ? a.wa.out_stride : C;
   // exp table of the log-int-softmax (as in k_lis_attention); entry 256 = clamp value (masked pairs), 257 = padding
   for (int t = tid; t < 258; t += (int)blockDim.x) {
     int xi = -t;
@@ -1310,7 +1311,7 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
   {
     const bool live = lane < N;
     const int rowj = a.wa.win_index[w * N + (live ? lane : 0)];
-    const int8_t* base = a.qkv + ((long long)b * a.T + rowj) * 3 * C + head * WA_HD;
+    const int8_t* base = a.qkv + ((long long)b * a.T + rowj) * ldq + head * WA_HD;
     uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0, v0 = k0, v1 = k0;
     if (live) {
       k0 = *reinterpret_cast<const uint4*>(base + C);
@@ -1340,7 +1341,7 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
     const int qi = qb * 16 + l15;
     const int qr = qi < N ? qi : N - 1;
     const int rowq = a.wa.win_index[w * N + qr];
-    const v4i qc = *reinterpret_cast<const v4i*>(a.qkv + ((long long)b * a.T + rowq) * 3 * C + head * WA_HD + (g & 1) * 16);
+    const v4i qc = *reinterpret_cast<const v4i*>(a.qkv + ((long long)b * a.T + rowq) * ldq + head * WA_HD + (g & 1) * 16);
     v4i qeta;
 #pragma unroll
     for (int d4 = 0; d4 < 4; ++d4) {
@@ -1440,7 +1441,7 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
       }
     }
     if (qi < N) {
-      int8_t* dst = a.out + ((long long)b * a.T + rowq) * C + head * WA_HD + 4 * g;
+      int8_t* dst = a.out + ((long long)b * a.T + rowq) * ldo + head * WA_HD + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
         *reinterpret_cast<unsigned*>(dst + dt * 16) =

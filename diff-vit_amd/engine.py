@@ -40,7 +40,7 @@ class Attn(C.Structure):
 
 class WinAttn(C.Structure):
     _fields_ = [('s_q1', _f), ('qk_scale', _f), ('s_attn', _f), ('s_table', _f), ('s_q2', _f), ('s_q3', _f), ('x0_int', _i),
-                ('b_int', _i), ('c_int', _i), ('table_codes', _p), ('win_index', _p), ('region', _p), ('ws', _i), ('n_windows', _i)]
+                ('b_int', _i), ('c_int', _i), ('table_codes', _p), ('win_index', _p), ('region', _p), ('ws', _i), ('n_windows', _i), ('qkv_stride', _i), ('out_stride', _i)]
 
 
 class Epilogue(C.Structure):

@@ -76,7 +76,7 @@ class SwinPlan:
         s_w = self.c[name][bt].reshape(-1)
         lo, hi = (-128, 127) if self.bits == 8 else (-8, 7)
         codes = torch.clamp(torch.round(w2 / s_w.reshape(-1, 1)), lo, hi)
-        kp = k_pad or K
+        kp = k_pad or (K + 63) // 64 * 64          # the GEMM walks 64-deep k-tiles: extra weight columns are zero
         wp = torch.zeros(_pad128(N), kp, dtype=torch.int8)
         wp[:N, :K] = codes.to(torch.int8)
         cs = torch.zeros(_pad128(N))
@@ -191,10 +191,13 @@ class SwinPlan:
                                     E.ptr(out_codes) if out_codes is not None else None, E.stream_ptr()))
         return out
 
-    def _layernorm(self, x, ln):
-        rows, Cc = x.shape
-        out = torch.empty_like(x)
-        E.check(E.lib().p2v_int_layernorm(E.ptr(x), Cc, rows, Cc, C.byref(ln), E.ptr(out), Cc, E.stream_ptr()))
+    def _layernorm(self, x, ln, Cc=None, pad=False):
+        """x [rows, >= Cc] (row stride = x.shape[1]).  pad: the output rows are padded to a multiple of 64 bytes so that the
+        GEMM that reads them can use whole k-tiles (the padding meets zero weight columns, its content is irrelevant)."""
+        rows, ld = x.shape
+        Cc = Cc or ld
+        out = torch.empty(rows, (Cc + 63) // 64 * 64 if pad else Cc, dtype=torch.int8, device=self.device)
+        E.check(E.lib().p2v_int_layernorm(E.ptr(x), ld, rows, Cc, C.byref(ln), E.ptr(out), out.shape[1], E.stream_ptr()))
         return out
 
     def forward(self, images, taps=None):
@@ -224,17 +227,18 @@ class SwinPlan:
             T = stg['H'] * stg['H']
             for bi, b in enumerate(stg['blocks']):
                 p = 'layers.%d.blocks.%d.' % (li, bi)
-                ln = self._layernorm(x, b['ln1'])
+                ln = self._layernorm(x, b['ln1'], b['C'], pad=True)
                 tap(p + 'qact1', ln)
                 epi = E.Epilogue()
                 epi.inv_s_out = b['inv_s_qkv']
                 qkv = self._gemm(E.EPI_REQUANT, ln, b['qkv'], epi)
-                att = torch.empty(B * T, b['C'], dtype=torch.int8, device=self.device)
+                att = torch.empty(B * T, (b['C'] + 63) // 64 * 64, dtype=torch.int8, device=self.device)
+                b['wa'].out_stride = att.shape[1]
                 E.check(L.p2v_window_attention(E.ptr(qkv), B, T, b['heads'], 32, C.byref(b['wa']), E.ptr(att), None, st))
                 b['proj_epi'].residual = C.cast(E.ptr(x), C.c_void_p)
                 x2 = self._gemm(E.EPI_RESID, att, b['proj'], b['proj_epi'])
                 tap(p + 'qact2', x2)
-                ln = self._layernorm(x2, b['ln2'])
+                ln = self._layernorm(x2, b['ln2'], b['C'], pad=True)
                 epi = E.Epilogue()
                 epi.inv_s_out = b['inv_s_fc1']
                 hid = self._gemm(E.EPI_GELU, ln, b['fc1'], epi)

@@ -212,6 +212,8 @@ typedef struct p2v_winattn {
   const int8_t* region;         /* dev [n_windows][ws*ws] shifted-window region ids, or NULL (no mask): pairs from different
                                  * regions get -100 (swin_quant.py:325-349)                                                   */
   int32_t ws, n_windows;
+  int32_t qkv_stride;           /* bytes between qkv rows (0 = dense: 3*heads*head_dim)                  */
+  int32_t out_stride;           /* bytes between out rows (0 = dense: heads*head_dim); lets the next GEMM read K padded to 64 */
 } p2v_winattn;
 
 /* qkv int8 [batch][tokens_per_image][3*heads*head_dim] (qact1 codes, natural token order); out int8

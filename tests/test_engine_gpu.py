@@ -538,3 +538,22 @@ def test_swin_base_engine_vs_oracle(dva, oracle):
         torch.cuda.synchronize()
         ref = SO.OracleSwin(m.arch, {k: v.cpu() for k, v in m.state_dict().items()}).quant_forward(x, m.export_calib(), 8)
     assert torch.equal(out.cpu(), ref), int((out.cpu() != ref).sum())
+
+
+def test_swin_tiny_k96_engine_vs_oracle(dva, oracle):
+    """Swin-T: embed_dim 96 (K = 96 GEMMs run on k-tiles of 64 through zero weight columns and padded row strides), heads 3..24,
+    1536-channel merge LayerNorm.  One image, all logits."""
+    import swin_oracle as SO
+    from diff_vit_amd import swin
+    S = dva.synth
+    m = swin.swin_tiny_patch4_window7_224(cfg=dva.Config(True, True, 'minmax')).eval()
+    m.load_state_dict(S.swin_state_dict(m.state_dict(), 8))
+    x = S.images(8, 2, 224)
+    m.cuda()
+    with torch.no_grad():
+        m.model_open_calibrate(); m.model_open_last_calibrate(); m(x.cuda()); m.model_close_calibrate()
+        m.model_quant()
+        out = m(x[:1].cuda())
+        torch.cuda.synchronize()
+        ref = SO.OracleSwin(m.arch, {k: v.cpu() for k, v in m.state_dict().items()}).quant_forward(x[:1], m.export_calib(), 8)
+    assert torch.equal(out.cpu(), ref), int((out.cpu() != ref).sum())
