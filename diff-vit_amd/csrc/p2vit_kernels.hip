@@ -438,10 +438,8 @@ __device__ __forceinline__ void gemm_compute_tile_w4(const int8_t* cx, const int
   do {                                                                                          \
     if (g.stamps && threadIdx.x == 0) g.stamps[(long long)blockIdx.x * 6 + (slot)] = __builtin_readcyclecounter(); \
   } while (0)
-// RING = depth of the register staging ring.  RING 2 fits 128 VGPRs (2-4 spilled dwords outside the k loop) -> 4 workgroups
-// per CU: fewer loads in flight per workgroup, but a fourth wave per SIMD for the VALU-bound epilogues.
-template <int EPI, int RING>
-__global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void k_gemm_i8_w4(GemmArgs g) {
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void k_gemm_i8_w4(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) int8_t lds[2 * (GBM + GBN) * GBK + sizeof(EpiLds)];
   int8_t* sX = lds;                    // [2][GBM][GBK] activation rows
   int8_t* sW = lds + 2 * GBM * GBK;    // [2][GBN][GBK] weight rows
@@ -500,12 +498,12 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void k_gemm_i8_w4(GemmArgs 
     *reinterpret_cast<uint4*>(bw_ + o0) = P##w0;                            \
     *reinterpret_cast<uint4*>(bw_ + o1) = P##w1;                            \
     __syncthreads();                                                        \
-    if ((T) + RING < nk) G_LOAD(P, (T) + RING);                                   \
+    if ((T) + 3 < nk) G_LOAD(P, (T) + 3);                                   \
     gemm_compute_tile_w4(bx_, bw_, wm, wn, l31, h, acc);                       \
   } while (0)
   G_LOAD(a, 0);
   if (nk > 1) G_LOAD(b, 1);
-  if (RING > 2 && nk > 2) G_LOAD(c, 2);
+  if (nk > 2) G_LOAD(c, 2);
   gemm_stage_epilogue<EPI>(sE, n0, tid, g);        // visible after the first barrier of the k loop
   if (g.dbg & 1) __syncthreads();
   uint4 resv[2][2];                                // residual codes of this lane's 4 output tiles, requested early
@@ -520,10 +518,10 @@ __global__ __launch_bounds__(256, RING == 2 ? 4 : 3) void k_gemm_i8_w4(GemmArgs 
       }
   }
   P2V_STAMP(1);
-  for (int kt = 0; kt < ((g.dbg & 1) ? 0 : nk); kt += RING) {
+  for (int kt = 0; kt < ((g.dbg & 1) ? 0 : nk); kt += 3) {
     G_STEP(a, kt);
     if (kt + 1 < nk) G_STEP(b, kt + 1);
-    if (RING > 2 && kt + 2 < nk) G_STEP(c, kt + 2);
+    if (kt + 2 < nk) G_STEP(c, kt + 2);
   }
 #undef G_LOAD
 #undef G_STEP
@@ -1494,7 +1492,6 @@ __global__ __launch_bounds__(256) void k_gelu_err_sweep(unsigned first_bits, uns
 // host launchers (called from the C ABI in p2vit_capi.cpp)
 // ---------------------------------------------------------------------------------------------------
 int g_gemm_dbg = 0;
-int g_gemm_ring2 = 0;     // P2V_GEMM_RING2 bit mask: 1 = qkv (REQUANT), 2 = fc1 (GELU) use the 2-deep ring at 4 workgroups/CU
 int g_attn_waves = 8;     // P2V_ATTN_WAVES
 unsigned long long* g_gemm_stamps = nullptr;
 int g_gemm_stagger = 0;  // P2V_GEMM_STAGGER=n
@@ -1605,15 +1602,9 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   if (g_gemm_waves == 4 && epi != P2V_EPI_HEAD && epi != P2V_EPI_EMBED) {
     dim3 grid4(g.tiles_n * tiles_m), block4(256);
     switch (epi) {
-      case P2V_EPI_REQUANT:
-        if (g_gemm_ring2 & 1) hipLaunchKernelGGL((k_gemm_i8_w4<P2V_EPI_REQUANT, 2>), grid4, block4, 0, st, g);
-        else hipLaunchKernelGGL((k_gemm_i8_w4<P2V_EPI_REQUANT, 3>), grid4, block4, 0, st, g);
-        break;
-      case P2V_EPI_GELU:
-        if (g_gemm_ring2 & 2) hipLaunchKernelGGL((k_gemm_i8_w4<P2V_EPI_GELU, 2>), grid4, block4, 0, st, g);
-        else hipLaunchKernelGGL((k_gemm_i8_w4<P2V_EPI_GELU, 3>), grid4, block4, 0, st, g);
-        break;
-      default: hipLaunchKernelGGL((k_gemm_i8_w4<P2V_EPI_RESID, 3>), grid4, block4, 0, st, g); break;
+      case P2V_EPI_REQUANT: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_REQUANT>, grid4, block4, 0, st, g); break;
+      case P2V_EPI_GELU: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_GELU>, grid4, block4, 0, st, g); break;
+      default: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_RESID>, grid4, block4, 0, st, g); break;
     }
     CHECK_LAUNCH();
     return 0;
