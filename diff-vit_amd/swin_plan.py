@@ -39,6 +39,8 @@ class SwinPlan:
         self.arch, self.device, self.in_chans, self.bits = dict(arch), torch.device(device), in_chans, bits
         if self.device.type != 'cuda':
             raise RuntimeError('SwinPlan needs a GPU device: the quantized forward has no CPU path')
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         E.lib()
         self._keep = []
         self.W = {k: v.detach().float().cpu() for k, v in state_dict.items() if v.dtype == torch.float32}

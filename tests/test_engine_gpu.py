@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP engine (through the C ABI) against the oracle and the reference golden vectors.
 Bit-exact: every comparison below is integer equality."""
 import ctypes as C
+from functools import partial
 
 import numpy as np
 import pytest
@@ -557,3 +558,31 @@ def test_swin_tiny_k96_engine_vs_oracle(dva, oracle):
         torch.cuda.synchronize()
         ref = SO.OracleSwin(m.arch, {k: v.cpu() for k, v in m.state_dict().items()}).quant_forward(x[:1], m.export_calib(), 8)
     assert torch.equal(out.cpu(), ref), int((out.cpu() != ref).sum())
+
+
+def test_plan_file_roundtrip(dva, micro, tmp_path):
+    """save_plan / load_plan: the plan rebuilt from the .npz gives the same logits as the live model, ViT and Swin."""
+    from diff_vit_amd import calib_io
+    cfg = dva.Config(True, True, 'minmax')
+    arch = micro['arch']
+    m = dva.VisionTransformer(img_size=arch['img_size'], patch_size=arch['patch_size'], embed_dim=arch['embed_dim'], depth=arch['depth'],
+                              num_heads=arch['num_heads'], num_classes=arch['num_classes'], mlp_ratio=arch['mlp_ratio'], qkv_bias=True,
+                              norm_layer=partial(dva.QIntLayerNorm, eps=1e-6), input_quant=True, cfg=cfg).eval()
+    m.load_state_dict(micro['sd'], strict=False)
+    x = micro['x_ev']
+    bits = [8] * (4 * arch['depth'] + 2)
+    with torch.no_grad():
+        dva.harness.calibrate_model(m, micro['x_cal'])
+        m.cuda()
+        want = m(x.cuda(), bits)[0].cpu()
+    calib_io.save_plan(str(tmp_path / 'vit.npz'), m)
+    plan = calib_io.load_plan(str(tmp_path / 'vit.npz'))
+    assert torch.equal(plan.forward(x.cuda(), bits).cpu(), want)
+    ms, xs = _micro_swin(dva)
+    with torch.no_grad():
+        ms.model_open_calibrate(); ms.model_open_last_calibrate(); ms(xs[:2]); ms.model_close_calibrate(); ms.model_quant()
+        ms.cuda()
+        want = ms(xs.cuda()).cpu()
+    calib_io.save_plan(str(tmp_path / 'swin.npz'), ms)
+    plan = calib_io.load_plan(str(tmp_path / 'swin.npz'))
+    assert torch.equal(plan.forward(xs.cuda()).cpu(), want)
