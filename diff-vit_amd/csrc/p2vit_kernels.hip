@@ -731,7 +731,7 @@ __device__ __forceinline__ uint4 gemm_epilogue_tile_res(const v16i& acc, int nl,
 // 4 (m) x 4 (n) waves of 64 x 32 outputs, <= 128 VGPRs.
 template <int EPI>
 __global__ __launch_bounds__(1024, 4) void k_gemm_resident(GemmArgs g, int tiles_total, int tiles_per_block) {
-  constexpr int KP = 384, NKT = KP / GBK, CPR = KP / 16;      // k-tiles, 16-byte chunks per row
+  constexpr int KP = 384, NKT = KP / GBK;                      // k-tiles
   constexpr int ATILE = RBM * GBK, WTILE = GBN * GBK;
   extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
   int8_t* sA = reinterpret_cast<int8_t*>(rsm);                 // [NKT][256][64] swizzled
