@@ -1,7 +1,7 @@
 """p2vit-mi355x: MI355X-native PoT-PTQ quantized ViT forward -- a drop-in for the quantized inference path of
 LeSN-Lab/diff-ViT (models/ptq + models/vit_fquant + config).  ``from diff_vit_amd import *`` yields what the
 reference's ``from models import *`` + ``from config import Config`` yield for this path.  See DESIGN.md."""
-from . import synth, engine, calib_io, dp, harness, search, ops  # noqa: F401
+from . import synth, engine, calib_io, checkpoint, dp, harness, search, ops  # noqa: F401
 from .config import Config  # noqa: F401
 from .plan import FrozenPlan  # noqa: F401
 from .ptq import BIT_TYPE_DICT, QAct, QConv2d, QIntLayerNorm, QIntSoftmax, QLinear  # noqa: F401

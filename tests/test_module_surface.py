@@ -140,3 +140,27 @@ def test_deit_small_calibration_identical_to_reference(dva):
     gdn = np.array([[float(v) for v in row] for row in gd])
     assert np.allclose(gdn, g['global_distance'], rtol=1e-5, atol=0)
     assert flops == [int(v) for v in g['flops']]
+
+
+def test_local_checkpoint_ingestion(tmp_path, synth):
+    """checkpoint.load_checkpoint: a DeiT-style .pth (state_dict under 'model') and a Flax-layout .npz (synthetic round trip)."""
+    import diff_vit_amd as dva
+    from diff_vit_amd import checkpoint
+    arch = synth.ARCHS['micro']
+    sd = synth.vit_state_dict(arch, 31)
+    mk = lambda: dva.VisionTransformer(img_size=arch['img_size'], patch_size=arch['patch_size'], embed_dim=arch['embed_dim'],  # noqa: E731
+                                       depth=arch['depth'], num_heads=arch['num_heads'], num_classes=arch['num_classes'],
+                                       mlp_ratio=arch['mlp_ratio'], qkv_bias=True, cfg=dva.Config(True, True, 'minmax'))
+    torch.save({'model': sd}, str(tmp_path / 'w.pth'))
+    np.savez(str(tmp_path / 'w.npz'), **checkpoint.state_dict_to_vit_npz(sd, arch['depth'], arch['num_heads']))
+    for name in ('w.pth', 'w.npz'):
+        m = mk()
+        res = checkpoint.load_checkpoint(m, str(tmp_path / name))
+        assert not res.unexpected_keys
+        got = m.state_dict()
+        for k, v in sd.items():
+            assert torch.equal(got[k], v), (name, k)
+    with pytest.raises(ValueError):
+        bad = dict(sd); bad['head.weight'] = torch.zeros(3, 3)
+        torch.save(bad, str(tmp_path / 'bad.pth'))
+        checkpoint.load_checkpoint(mk(), str(tmp_path / 'bad.pth'))
