@@ -450,8 +450,12 @@ class VisionTransformer(nn.Module):
             # ---- THE HOT PATH: fused HIP engine -----------------------------------------------------------------
             if bit_config is None:
                 raise ValueError('None is not in list')          # bit_pool.index(None), vit_fquant.py:282
-            if any(int(b) == -1 for b in bit_config):
-                raise NotImplementedError('per-layer fp fallback (bit_config == -1) is not part of the fused engine yet')
+            if any(int(b) == -1 for b in bit_config[1:-1]):
+                # the reference looks the block's bit up in bit_pool before anything else (vit_fquant.py:282, layers_quant.py
+                # SmoothQuant lookup): -1 raises there too (its own comments note the -1 path ends in NaN, vit_fquant.py:465-466)
+                raise ValueError('-1 is not in list')
+            if int(bit_config[0]) == -1 or int(bit_config[-1]) == -1:
+                raise NotImplementedError('fp32 patch-embed / head (bit_config == -1, layers.py:144,171) is not part of the fused engine')
             if self._plan is None:
                 self.freeze(x.device if x.is_cuda else None)
             return self._plan.forward(x, [int(b) for b in bit_config]), self.flops(), []

@@ -164,3 +164,22 @@ def test_local_checkpoint_ingestion(tmp_path, synth):
         bad = dict(sd); bad['head.weight'] = torch.zeros(3, 3)
         torch.save(bad, str(tmp_path / 'bad.pth'))
         checkpoint.load_checkpoint(mk(), str(tmp_path / 'bad.pth'))
+
+
+def test_minus_one_bit_config_error_convention(synth):
+    """bit_config == -1 in a block position raises ValueError before any engine call, like bit_pool.index(-1) does in the
+    reference (vit_fquant.py:282); -1 for the patch embed / head is NotImplementedError (no fp32 layer in the fused engine)."""
+    import diff_vit_amd as dva
+    arch = synth.ARCHS['micro']
+    m = dva.VisionTransformer(img_size=arch['img_size'], patch_size=arch['patch_size'], embed_dim=arch['embed_dim'], depth=arch['depth'],
+                              num_heads=arch['num_heads'], num_classes=arch['num_classes'], mlp_ratio=arch['mlp_ratio'], qkv_bias=True,
+                              cfg=dva.Config(True, True, 'minmax')).eval()
+    m.model_quant()
+    x = torch.zeros(1, 3, arch['img_size'], arch['img_size'])
+    L = 4 * arch['depth'] + 2
+    with pytest.raises(ValueError):
+        m(x, [8, -1] + [8] * (L - 2))
+    with pytest.raises(NotImplementedError):
+        m(x, [-1] + [8] * (L - 1))
+    with pytest.raises(ValueError):
+        m(x, None)
