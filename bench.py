@@ -9,6 +9,7 @@ synthetic images per GPU, followed -- when N>1 -- by the single RCCL all-gather 
 (SURVEY.md 8e).  Weak scaling: per-GPU batch fixed.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -79,7 +80,8 @@ def main():
     # the reference's flow through the drop-in surface: build, load, calibrate (float pass + observers, on the GPU),
     # model_quant(); the first quantized forward freezes the integer plan.  Calibration batch = the one the REAL
     # reference was calibrated on for tests/golden/deit_small.npz, so the resulting scales can be compared.
-    model = dva.harness.str2model(args.model)(cfg=dva.Config(True, True, 'minmax'))
+    with contextlib.redirect_stdout(sys.stderr):          # stdout carries exactly one JSON line
+        model = dva.harness.str2model(args.model)(cfg=dva.Config(True, True, 'minmax'))
     model.load_state_dict(sd, strict=False)
     model = model.to(dev).eval()
     t_cal = time.perf_counter()
