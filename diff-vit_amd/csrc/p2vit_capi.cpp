@@ -397,6 +397,53 @@ int p2v_window_attention(const int8_t* qkv, int batch, int tokens_per_image, int
   return launch_rc(p2v_launch_window_attention(a, (hipStream_t)stream), "window_attention");
 }
 
+static int run_one_op(const p2v_op& o, void* stream) {
+  switch (o.kind) {
+    case P2V_OP_PATCHIFY:
+      return p2v_quantize_patchify((const float*)o.in, o.i0, o.i1, o.i2, o.i3, o.i4, o.f0, (int8_t*)o.out, o.i5, stream);
+    case P2V_OP_GEMM:
+      return p2v_gemm_i8(o.epi, (const int8_t*)o.in, o.lda, o.M, o.K, o.N, &o.lin, &o.ep, o.out, o.ldo, nullptr, stream);
+    case P2V_OP_LAYERNORM:
+      return p2v_int_layernorm((const int8_t*)o.in, o.lda, o.M, o.N, &o.ln, (int8_t*)o.out, o.ldo, stream);
+    case P2V_OP_WINATTN:
+      return p2v_window_attention((const int8_t*)o.in, o.i0, o.i1, o.i2, o.i3, &o.wa, (int8_t*)o.out, nullptr, stream);
+    case P2V_OP_MERGE:
+      return p2v_patch_merge_gather((const int8_t*)o.in, o.i0, o.i1, o.i2, o.i3, (int8_t*)o.out, stream);
+    case P2V_OP_AVGPOOL:
+      return p2v_avgpool_quant((const int8_t*)o.in, o.i0, o.i1, o.i2, o.f0, o.f1, (int8_t*)o.out, stream);
+    default:
+      return fail(P2V_E_ARG, "p2v_run_ops: unknown op kind %d", o.kind);
+  }
+}
+
+int p2v_run_ops(const p2v_op* ops, int n_ops, void* stream) {
+  if (!ops || n_ops < 0) return fail(P2V_E_ARG, "p2v_run_ops: null argument");
+  for (int i = 0; i < n_ops; ++i) {
+    const int rc = run_one_op(ops[i], stream);
+    if (rc != P2V_OK) return rc;
+  }
+  return P2V_OK;
+}
+
+int p2v_run_ops_profile(const p2v_op* ops, int n_ops, void* stream, float* ms) {
+  if (!ops || !ms || n_ops < 0) return fail(P2V_E_ARG, "p2v_run_ops_profile: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev(n_ops + 1);
+  for (auto& e : ev) hipEventCreate(&e);
+  int rc = P2V_OK;
+  hipEventRecord(ev[0], st);
+  int done = 0;
+  for (; done < n_ops; ++done) {
+    rc = run_one_op(ops[done], stream);
+    if (rc != P2V_OK) break;
+    hipEventRecord(ev[done + 1], st);
+  }
+  hipStreamSynchronize(st);
+  for (int i = 0; i < done; ++i) hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+  for (auto& e : ev) hipEventDestroy(e);
+  return rc;
+}
+
 int p2v_fake_quant_f32(const float* x, long long n, const float* scale, int n_scale, long long inner, int lo, int hi, float* out,
                        int8_t* codes, void* stream) {
   if (!x || !scale || (!out && !codes)) return fail(P2V_E_ARG, "p2v_fake_quant_f32: null argument");

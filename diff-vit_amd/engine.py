@@ -53,6 +53,16 @@ class Block(C.Structure):
                 ('inv_s_fc1', _f), ('fc2_epi', Epilogue)]
 
 
+OP_PATCHIFY, OP_GEMM, OP_LAYERNORM, OP_WINATTN, OP_MERGE, OP_AVGPOOL = range(6)
+
+
+class Op(C.Structure):
+    """one record of a replayable launch sequence (``p2v_op`` in include/p2vit.h)."""
+    _fields_ = [('kind', _i), ('epi', _i), ('inp', _p), ('out', _p), ('M', _i), ('K', _i), ('N', _i), ('lda', _i), ('ldo', _i),
+                ('i0', _i), ('i1', _i), ('i2', _i), ('i3', _i), ('i4', _i), ('i5', _i), ('f0', _f), ('f1', _f),
+                ('lin', Linear), ('ep', Epilogue), ('ln', Ln), ('wa', WinAttn)]
+
+
 class P2VError(RuntimeError):
     pass
 
@@ -93,6 +103,8 @@ def lib():
     L.p2v_gemm_i8.argtypes = [_i, _p, _i, _i, _i, _i, C.POINTER(Linear), C.POINTER(Epilogue), _p, _i, _p, _p]
     L.p2v_int_layernorm.argtypes = [_p, _ll, _i, _i, C.POINTER(Ln), _p, _ll, _p]
     L.p2v_lis_attention.argtypes = [_p, _i, _i, _i, _i, C.POINTER(Attn), _p, _p, _p]
+    L.p2v_run_ops.argtypes = [C.POINTER(Op), _i, _p]
+    L.p2v_run_ops_profile.argtypes = [C.POINTER(Op), _i, _p, C.POINTER(C.c_float)]
     L.p2v_patch_merge_gather.argtypes = [_p, _i, _i, _i, _i, _p, _p]
     L.p2v_avgpool_quant.argtypes = [_p, _i, _i, _i, _f, _f, _p, _p]
     L.p2v_window_attention.argtypes = [_p, _i, _i, _i, _i, C.POINTER(WinAttn), _p, _p, _p]

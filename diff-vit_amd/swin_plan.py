@@ -45,6 +45,7 @@ class SwinPlan:
         self._keep = []
         self.W = {k: v.detach().float().cpu() for k, v in state_dict.items() if v.dtype == torch.float32}
         self.c = calib
+        self._recorded = {}
         self._build()
 
     # ---- helpers -------------------------------------------------------------------------------------------------------
@@ -185,84 +186,171 @@ class SwinPlan:
         return e
 
     # ---- forward -------------------------------------------------------------------------------------------------------
-    def _gemm(self, kind, x, lin, epi, out_dtype=torch.int8, out_codes=None):
-        M, K = x.shape
-        N = lin['N']
-        out = torch.empty(M, N, dtype=out_dtype, device=self.device)
-        E.check(E.lib().p2v_gemm_i8(kind, E.ptr(x), K, M, K, N, C.byref(lin['lin']), C.byref(epi), E.ptr(out), N,
-                                    E.ptr(out_codes) if out_codes is not None else None, E.stream_ptr()))
+    def _record(self, B):
+        """the launch sequence of one forward at batch B as a ``p2v_op`` array with its own activation buffers (built once
+        per batch size and stream slot, replayed by ``p2v_run_ops``)."""
+        a = self.arch
+        P, g = a['patch_size'], self.g
+        dev = self.device
+        ops, taps, keep = [], [], []
+
+        def buf(rows, cols, zero=False):
+            t_ = (torch.zeros if zero else torch.empty)(rows, cols, dtype=torch.int8, device=dev)
+            keep.append(t_)
+            return t_
+
+        def pad64(n):
+            return (n + 63) // 64 * 64
+
+        def gemm(kind, x, lin, epi, out):
+            o = E.Op()
+            o.kind, o.epi, o.inp, o.out = E.OP_GEMM, kind, E.ptr(x), E.ptr(out)
+            o.M, o.K, o.N, o.lda, o.ldo = x.shape[0], x.shape[1], lin['N'], x.shape[1], lin['N']
+            o.lin, o.ep = lin['lin'], epi
+            ops.append(o)
+            return out
+
+        def lnorm(x, ln, Cc, out):
+            o = E.Op()
+            o.kind, o.inp, o.out = E.OP_LAYERNORM, E.ptr(x), E.ptr(out)
+            o.M, o.N, o.lda, o.ldo, o.ln = x.shape[0], Cc, x.shape[1], out.shape[1], ln
+            ops.append(o)
+            return out
+
+        def epi_req(inv_s):
+            e = E.Epilogue()
+            e.inv_s_out = inv_s
+            return e
+
+        def epi_res(src, residual):
+            e = E.Epilogue()
+            e.s_mid, e.s_res, e.s_next, e.residual = src.s_mid, src.s_res, src.s_next, E.ptr(residual)
+            return e
+
+        o = E.Op()
+        patches = buf(B * g * g, self.k_patch, zero=True)
+        o.kind, o.out = E.OP_PATCHIFY, E.ptr(patches)
+        o.i0, o.i1, o.i2, o.i3, o.i4, o.i5, o.f0 = B, self.in_chans, a['img_size'], a['img_size'], P, self.k_patch, 1.0 / self.s_in
+        ops.append(o)
+        D0 = a['embed_dim']
+        pe = gemm(E.EPI_REQUANT, patches, self.pe, epi_req(1.0 / self.s_pe_b), buf(B * g * g, D0))
+        x = lnorm(pe, self.pe_ln, D0, buf(B * g * g, D0))
+        taps.append((len(ops), 'patch_embed.qact', x))
+        for li, stg in enumerate(self.stages):
+            T, Cc = stg['H'] * stg['H'], stg['C']
+            rows = B * T
+            x2 = buf(rows, Cc)
+            ln = buf(rows, pad64(Cc))
+            qkv = buf(rows, 3 * Cc)
+            att = buf(rows, pad64(Cc))
+            hid = buf(rows, 4 * Cc)
+            for bi, b in enumerate(stg['blocks']):
+                p = 'layers.%d.blocks.%d.' % (li, bi)
+                lnorm(x, b['ln1'], Cc, ln)
+                taps.append((len(ops), p + 'qact1', ln))
+                gemm(E.EPI_REQUANT, ln, b['qkv'], epi_req(b['inv_s_qkv']), qkv)
+                o = E.Op()
+                o.kind, o.inp, o.out = E.OP_WINATTN, E.ptr(qkv), E.ptr(att)
+                o.i0, o.i1, o.i2, o.i3 = B, T, b['heads'], 32
+                o.wa = b['wa']
+                o.wa.out_stride = att.shape[1]
+                ops.append(o)
+                gemm(E.EPI_RESID, att, b['proj'], epi_res(b['proj_epi'], x), x2)
+                taps.append((len(ops), p + 'qact2', x2))
+                lnorm(x2, b['ln2'], Cc, ln)
+                gemm(E.EPI_GELU, ln, b['fc1'], epi_req(b['inv_s_fc1']), hid)
+                gemm(E.EPI_RESID, hid, b['fc2'], epi_res(b['fc2_epi'], x2), x)
+                taps.append((len(ops), p + 'qact4', x))
+            if stg['merge'] is not None:
+                m, H = stg['merge'], stg['H']
+                r2 = B * (H // 2) * (H // 2)
+                gathered = buf(r2, 4 * Cc)
+                o = E.Op()
+                o.kind, o.inp, o.out = E.OP_MERGE, E.ptr(x), E.ptr(gathered)
+                o.i0, o.i1, o.i2, o.i3 = B, H, H, Cc
+                ops.append(o)
+                lnm = lnorm(gathered, m['ln'], 4 * Cc, buf(r2, 4 * Cc))
+                x = gemm(E.EPI_RESID, lnm, m['red'], epi_res(m['epi'], buf(r2, 2 * Cc, zero=True)), buf(r2, 2 * Cc))
+                taps.append((len(ops), 'layers.%d.downsample.qact2' % li, x))
+        fin = lnorm(x, self.fin_ln, self.C_last, buf(x.shape[0], self.C_last))
+        taps.append((len(ops), 'qact2', fin))
+        pooled = buf(B, self.C_last)
+        o = E.Op()
+        o.kind, o.inp, o.out = E.OP_AVGPOOL, E.ptr(fin), E.ptr(pooled)
+        o.i0, o.i1, o.i2, o.f0, o.f1 = B, self.H_last * self.H_last, self.C_last, self.s_f, 1.0 / self.s_pool
+        ops.append(o)
+        taps.append((len(ops), 'qact3', pooled))
+        e = E.Epilogue()
+        e.inv_s_out, e.s_out = 1.0 / self.s_out, self.s_out
+        o = E.Op()
+        o.kind, o.epi, o.inp = E.OP_GEMM, E.EPI_HEAD, E.ptr(pooled)
+        o.M, o.K, o.N, o.lda, o.ldo = B, self.C_last, self.head['N'], self.C_last, self.head['N']
+        o.lin, o.ep = self.head['lin'], e
+        ops.append(o)
+        arr = (E.Op * len(ops))(*ops)
+        return dict(ops=arr, n=len(ops), taps=taps, keep=keep)
+
+    def _replay(self, images, slot, taps=None, profile=False):
+        B = images.shape[0]
+        key = (B, slot)
+        if key not in self._recorded:
+            self._recorded[key] = self._record(B)
+        r = self._recorded[key]
+        out = torch.empty(B, self.head['N'], dtype=torch.float32, device=self.device)
+        r['ops'][0].inp = E.ptr(images)
+        r['ops'][r['n'] - 1].out = E.ptr(out)
+        L = E.lib()
+        if profile:
+            ms = (C.c_float * r['n'])()
+            E.check(L.p2v_run_ops_profile(r['ops'], r['n'], E.stream_ptr(), ms))
+            return out, list(ms)
+        if taps is None:
+            E.check(L.p2v_run_ops(r['ops'], r['n'], E.stream_ptr()))
+            return out
+        done = 0
+        for upto, name, t_ in r['taps']:          # replay in segments and copy the tapped buffers (they are reused later)
+            E.check(L.p2v_run_ops(C.cast(C.byref(r['ops'], done * C.sizeof(E.Op)), C.POINTER(E.Op)), upto - done, E.stream_ptr()))
+            taps[name] = t_[:, :t_.shape[1]].clone()
+            done = upto
+        E.check(L.p2v_run_ops(C.cast(C.byref(r['ops'], done * C.sizeof(E.Op)), C.POINTER(E.Op)), r['n'] - done, E.stream_ptr()))
         return out
 
-    def _layernorm(self, x, ln, Cc=None, pad=False):
-        """x [rows, >= Cc] (row stride = x.shape[1]).  pad: the output rows are padded to a multiple of 64 bytes so that the
-        GEMM that reads them can use whole k-tiles (the padding meets zero weight columns, its content is irrelevant)."""
-        rows, ld = x.shape
-        Cc = Cc or ld
-        out = torch.empty(rows, (Cc + 63) // 64 * 64 if pad else Cc, dtype=torch.int8, device=self.device)
-        E.check(E.lib().p2v_int_layernorm(E.ptr(x), ld, rows, Cc, C.byref(ln), E.ptr(out), out.shape[1], E.stream_ptr()))
-        return out
-
-    def forward(self, images, taps=None):
-        """images fp32 [B, in_chans, S, S] on the plan's device -> logits fp32 [B, classes] (act_out grid)."""
+    def _check_images(self, images):
+        a = self.arch
         images = images.contiguous().float()
         if images.device != self.device:
             raise RuntimeError('images must live on %s' % self.device)
-        L = E.lib()
-        a = self.arch
-        B, P, g = images.shape[0], a['patch_size'], self.g
         if tuple(images.shape[1:]) != (self.in_chans, a['img_size'], a['img_size']):
             raise AssertionError("Input image size (%d*%d) doesn't match model (%d*%d)." % (images.shape[2], images.shape[3], a['img_size'], a['img_size']))
-        st = E.stream_ptr()
+        return images
 
-        def tap(name, t):
-            if taps is not None:
-                taps[name] = t.clone()
-        patches = torch.zeros(B * g * g, self.k_patch, dtype=torch.int8, device=self.device)
-        E.check(L.p2v_quantize_patchify(E.ptr(images), B, self.in_chans, a['img_size'], a['img_size'], P, 1.0 / self.s_in, E.ptr(patches),
-                                        self.k_patch, st))
-        epi = E.Epilogue()
-        epi.inv_s_out = 1.0 / self.s_pe_b
-        x = self._layernorm(self._gemm(E.EPI_REQUANT, patches, self.pe, epi), self.pe_ln)
-        tap('patch_embed.qact', x)
-        zero_res = None
-        for li, stg in enumerate(self.stages):
-            T = stg['H'] * stg['H']
-            for bi, b in enumerate(stg['blocks']):
-                p = 'layers.%d.blocks.%d.' % (li, bi)
-                ln = self._layernorm(x, b['ln1'], b['C'], pad=True)
-                tap(p + 'qact1', ln)
-                epi = E.Epilogue()
-                epi.inv_s_out = b['inv_s_qkv']
-                qkv = self._gemm(E.EPI_REQUANT, ln, b['qkv'], epi)
-                att = torch.empty(B * T, (b['C'] + 63) // 64 * 64, dtype=torch.int8, device=self.device)
-                b['wa'].out_stride = att.shape[1]
-                E.check(L.p2v_window_attention(E.ptr(qkv), B, T, b['heads'], 32, C.byref(b['wa']), E.ptr(att), None, st))
-                b['proj_epi'].residual = C.cast(E.ptr(x), C.c_void_p)
-                x2 = self._gemm(E.EPI_RESID, att, b['proj'], b['proj_epi'])
-                tap(p + 'qact2', x2)
-                ln = self._layernorm(x2, b['ln2'], b['C'], pad=True)
-                epi = E.Epilogue()
-                epi.inv_s_out = b['inv_s_fc1']
-                hid = self._gemm(E.EPI_GELU, ln, b['fc1'], epi)
-                b['fc2_epi'].residual = C.cast(E.ptr(x2), C.c_void_p)
-                x = self._gemm(E.EPI_RESID, hid, b['fc2'], b['fc2_epi'])
-                tap(p + 'qact4', x)
-            if stg['merge'] is not None:
-                m = stg['merge']
-                H = stg['H']
-                gathered = torch.empty(B * (H // 2) * (H // 2), 4 * stg['C'], dtype=torch.int8, device=self.device)
-                E.check(L.p2v_patch_merge_gather(E.ptr(x), B, H, H, stg['C'], E.ptr(gathered), st))
-                ln = self._layernorm(gathered, m['ln'])
-                zero_res = torch.zeros(ln.shape[0], 2 * stg['C'], dtype=torch.int8, device=self.device)
-                m['epi'].residual = C.cast(E.ptr(zero_res), C.c_void_p)
-                x = self._gemm(E.EPI_RESID, ln, m['red'], m['epi'])
-                tap('layers.%d.downsample.qact2' % li, x)
-        fin = self._layernorm(x, self.fin_ln)
-        tap('qact2', fin)
-        pooled = torch.empty(B, self.C_last, dtype=torch.int8, device=self.device)
-        E.check(L.p2v_avgpool_quant(E.ptr(fin), B, self.H_last * self.H_last, self.C_last, self.s_f, 1.0 / self.s_pool, E.ptr(pooled), st))
-        tap('qact3', pooled)
-        # the GEMM needs K % 64 == 0 rows of 16-byte alignment: C_last is a multiple of 64 for every Swin variant here
-        epi = E.Epilogue()
-        epi.inv_s_out, epi.s_out = 1.0 / self.s_out, self.s_out
-        return self._gemm(E.EPI_HEAD, pooled, self.head, epi, out_dtype=torch.float32)
+    def forward(self, images, taps=None, n_streams=2):
+        """images fp32 [B, in_chans, S, S] on the plan's device -> logits fp32 [B, classes] (act_out grid).  One C call replays
+        the recorded launch sequence; a large batch runs as ``n_streams`` contiguous slices on their own HIP streams (images are
+        independent), like the ViT plan."""
+        images = self._check_images(images)
+        B = images.shape[0]
+        if taps is not None or n_streams <= 1 or B < 16 * n_streams:
+            return self._replay(images, 0, taps)
+        if getattr(self, '_streams', None) is None or len(self._streams) != n_streams:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+        cur = torch.cuda.current_stream(self.device)
+        step = (B + n_streams - 1) // n_streams
+        outs = []
+        for i, st in enumerate(self._streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(self._replay(images[i * step:(i + 1) * step], i + 1))
+        for st in self._streams:
+            cur.wait_stream(st)
+        for o in outs:
+            o.record_stream(cur)
+        return torch.cat(outs, 0)
+
+    def profile(self, images):
+        """per-op durations (ms, HIP events on the launch stream) of one single-stream forward: [(kind, epilogue, ms), ...]."""
+        images = self._check_images(images)
+        _, ms = self._replay(images, 0, profile=True)
+        r = self._recorded[(images.shape[0], 0)]
+        names = ('patchify', 'gemm', 'layernorm', 'window_attention', 'merge_gather', 'avgpool')
+        return [(names[r['ops'][i].kind], int(r['ops'][i].epi), ms[i]) for i in range(r['n'])]

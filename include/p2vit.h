@@ -230,6 +230,34 @@ int p2v_patch_merge_gather(const int8_t* x, int batch, int H, int W, int C, int8
  * qact2 output (codes * s_in, power-of-two s_in: the sum is exact), then qact3: out[b][c] = clamp(round((sum*s_in / tokens) * inv_s_out)). */
 int p2v_avgpool_quant(const int8_t* x, int batch, int tokens, int C, float s_in, float inv_s_out, int8_t* out, void* stream);
 
+/* A recorded sequence of the per-operator entry points above, replayed by ONE call: the host-side cost of a forward with a
+ * few hundred launches (Swin: ~200) drops to one FFI crossing, and the sequence can be replayed on any stream.  Every record is
+ * plain data; pointers are device pointers borrowed for the call.  kind selects which members are read:
+ *   P2V_OP_PATCHIFY   in (fp32 images), out; i0 batch, i1 chans, i2 height, i3 width, i4 patch, i5 k_pad; f0 inv_s
+ *   P2V_OP_GEMM       in (A), out; epi; M, K, N, lda, ldo; lin; ep
+ *   P2V_OP_LAYERNORM  in, out; M rows, N channels, lda / ldo row strides; ln
+ *   P2V_OP_WINATTN    in (qkv), out; i0 batch, i1 tokens per image, i2 heads, i3 head_dim; wa
+ *   P2V_OP_MERGE      in, out; i0 batch, i1 H, i2 W, i3 C
+ *   P2V_OP_AVGPOOL    in, out; i0 batch, i1 tokens, i2 C; f0 s_in, f1 inv_s_out                                            */
+enum { P2V_OP_PATCHIFY = 0, P2V_OP_GEMM = 1, P2V_OP_LAYERNORM = 2, P2V_OP_WINATTN = 3, P2V_OP_MERGE = 4, P2V_OP_AVGPOOL = 5 };
+typedef struct p2v_op {
+  int32_t kind, epi;
+  const void* in;
+  void* out;
+  int32_t M, K, N, lda, ldo;
+  int32_t i0, i1, i2, i3, i4, i5;
+  float f0, f1;
+  p2v_linear lin;
+  p2v_epilogue ep;
+  p2v_ln ln;
+  p2v_winattn wa;
+} p2v_op;
+
+/* run ops[0..n_ops) in order on `stream`; stops at the first error (its status is returned, p2v_last_error names the op). */
+int p2v_run_ops(const p2v_op* ops, int n_ops, void* stream);
+/* same, with HIP events recorded on `stream` around every op: ms[i] = duration of op i (synchronises the stream). */
+int p2v_run_ops_profile(const p2v_op* ops, int n_ops, void* stream, float* ms);
+
 /* UniformQuantizer.forward on an fp32 tensor (uniform.py:50-127, base.py:42-45): fake-quant in place of
  * the eager round/clamp chain.  scale has `n_scale` entries (1 = layer-wise) applied along the channel
  * dimension: element i uses scale[(i / inner) % n_scale].  codes (optional) receives the int8 codes. */
