@@ -131,14 +131,19 @@ def main():
     value = world * B * args.steps / el
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, measured live ----------------------
+    # One LAUNCH in the timed region covers one batch slice (B / streams images, forward_streams): the profile pass times
+    # exactly those launches - same kernels, same shapes - with events recorded on the launch stream between consecutive
+    # launches, so its average agrees with the rocprofv3 --kernel-trace average of this command (profiles/).
+    n_sl = args.streams if (args.streams > 1 and B >= 2 * args.streams) else 1
+    Bl = (B + n_sl - 1) // n_sl
     prof = {}
     for _ in range(5):
-        for kind, ms in plan.profile(x, bits):
+        for kind, ms in plan.profile(x[:Bl], bits):
             prof.setdefault(kind, []).append(ms)
-    tot = {k: sum(v) / 5 for k, v in prof.items()}
+    tot = {k: n_sl * sum(v) / 5 for k, v in prof.items()}        # per step: every slice issues the same launches
     dom = max(tot, key=tot.get)
     avg_ms = sum(prof[dom]) / len(prof[dom])
-    ops, byts = algorithmic_work(dom, arch, B)
+    ops, byts = algorithmic_work(dom, arch, Bl)
     if ops > 0:
         ach = ops / (avg_ms * 1e-3) / 1e12
         roof = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=PEAK_INT8_TOPS, unit='TFLOP/s',
@@ -148,16 +153,20 @@ def main():
         roof = dict(kernel=dom, bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                     frac=round(ach / PEAK_HBM_GBS, 4))
     roof['avg_launch_us'] = round(avg_ms * 1e3, 2)
-    roof['launches_per_step'] = len(prof[dom]) // 5
+    roof['launches_per_step'] = n_sl * (len(prof[dom]) // 5)
+    roof['images_per_launch'] = Bl
+    roof['algorithmic_per_launch'] = {'ops': ops, 'bytes': byts}
     roof['traffic'] = None
     pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
-    if os.path.exists(pmc) and args.model == MODEL and B == BATCH:
+    if os.path.exists(pmc) and args.model == MODEL:
         try:
-            roof['traffic'] = json.load(open(pmc)).get(dom)
+            t = json.load(open(pmc))
+            if int(t.get('_images_per_launch', -1)) == Bl:
+                roof['traffic'] = t.get(dom)
         except Exception:
             pass
     breakdown = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
-    model_ops = sum(algorithmic_work(k, arch, B)[0] * (len(v) // 5) for k, v in prof.items())
+    model_ops = sum(algorithmic_work(k, arch, Bl)[0] * n_sl * (len(v) // 5) for k, v in prof.items())
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
