@@ -57,3 +57,27 @@ def test_custom_ops_registered_and_gpu_only():
         torch.ops.p2vit.fake_quant(torch.zeros(4), torch.ones(1), 1, -128, 127)
     with pytest.raises(NotImplementedError):
         torch.ops.p2vit.int_layernorm(torch.zeros(2, 64, dtype=torch.int8), 1.0, *[torch.ones(64)] * 5)
+
+
+def test_run_ops_and_swin_entry_validation_without_gpu():
+    """p2v_run_ops / window attention / merge / avgpool reject bad records before any HIP call."""
+    import diff_vit_amd
+    E = diff_vit_amd.engine
+    L = E.lib()
+    assert L.p2v_run_ops((E.Op * 1)(), 0, None) == 0                        # empty sequence
+    op = E.Op()
+    op.kind = 99
+    with pytest.raises(E.P2VError):
+        E.check(L.p2v_run_ops((E.Op * 1)(op), 1, None))
+    assert b'unknown op kind' in L.p2v_last_error()
+    one = ctypes.c_void_p(16)
+    wa = E.WinAttn(2.0 ** -4, 0.1767767, 2.0 ** -3, 2.0 ** -5, 2.0 ** -4, 2.0 ** -3, -12, 43, 714, one, one, None, 7, 4)
+    with pytest.raises(NotImplementedError):                                # head_dim 64: only 32 is instantiated
+        E.check(L.p2v_window_attention(one, 1, 196, 4, 64, ctypes.byref(wa), one, None, None))
+    wa.s_q2 = 0.3                                                           # not a power of two
+    with pytest.raises(NotImplementedError):
+        E.check(L.p2v_window_attention(one, 1, 196, 4, 32, ctypes.byref(wa), one, None, None))
+    with pytest.raises(AssertionError):                                     # odd feature map
+        E.check(L.p2v_patch_merge_gather(one, 1, 7, 7, 64, one, None))
+    with pytest.raises(NotImplementedError):
+        E.check(L.p2v_avgpool_quant(one, 1, 49, 6, 1.0, 1.0, one, None))
