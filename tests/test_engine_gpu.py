@@ -586,3 +586,24 @@ def test_plan_file_roundtrip(dva, micro, tmp_path):
     calib_io.save_plan(str(tmp_path / 'swin.npz'), ms)
     plan = calib_io.load_plan(str(tmp_path / 'swin.npz'))
     assert torch.equal(plan.forward(xs.cuda()).cpu(), want)
+
+
+def test_swin_batch_independence_and_stream_slices(dva):
+    """a 33-image batch (two stream slices of 17 + 16, recorded op lists per slice) gives the rows a 1-image and a 5-image call give."""
+    m, _ = _micro_swin(dva)
+    x = dva.synth.images(12, 33, 56)
+    with torch.no_grad():
+        m.model_open_calibrate(); m.model_open_last_calibrate(); m(x[:2]); m.model_close_calibrate()
+        m.model_quant()
+        m.cuda()
+        xc = x.cuda()
+        full = m(xc).cpu()
+        one = m(xc[20:21]).cpu()
+        five = m(xc[28:33]).cpu()
+        single_stream = m._plan.forward(xc, n_streams=1).cpu()
+    assert full.shape == (33, 10)
+    assert torch.equal(full[20:21], one) and torch.equal(full[28:33], five) and torch.equal(full, single_stream)
+    with pytest.raises(AssertionError):
+        m(torch.zeros(2, 3, 64, 64, device='cuda'))
+    with pytest.raises(RuntimeError):
+        m._plan.forward(x)                                   # CPU tensor: no fallback
