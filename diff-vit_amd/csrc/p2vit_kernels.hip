@@ -1267,6 +1267,10 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------------
 #define WA_HD 32
 #define WA_KEYS 64
+// NT = ws*ws when known at compile time (49 for the 7x7 windows of every Swin variant), 0 = generic.  A score slot (kb, r) holds
+// key kb*16 + 4g + r: when kb*16 + r >= NT it is padding in every lane and its arithmetic is dropped (3 of 16 slots at NT = 49).
+#define WA_DEAD(kb, r) (NT > 0 && (kb) * 16 + (r) >= NT)
+template <int NT>
 __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
   constexpr int VSTRIDE = WA_KEYS + 4;                                         // bf16 elements
   __shared__ __attribute__((aligned(16))) int8_t sK[4][WA_KEYS * WA_HD];
@@ -1371,6 +1375,7 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        if (WA_DEAD(kb, r)) continue;
         const int j = kb * 16 + 4 * g + r;
         const double e = __builtin_fma(sig_d, (double)s1[kb][r], (double)s2[kb][r] * u_d);      // exact
         const float attn = (float)e;                                                           // ONE rounding
@@ -1395,6 +1400,7 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        if (WA_DEAD(kb, r)) continue;
         const int j = kb * 16 + 4 * g + r;
         int d = mx - s1[kb][r];
         d = d > 256 ? 256 : d;
@@ -1416,6 +1422,10 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
         for (int e = 0; e < 2; ++e) {
           const int jj = 2 * e2 + e;
           const int kb = 2 * p + (jj >> 2), r = jj & 3;
+          if (WA_DEAD(kb, r)) {
+            hw2[e] = 0u;
+            continue;
+          }
           const float2 fr = lutFR[s1[kb][r]];
           const float r0 = Sf * fr.y;
           const float r1 = __builtin_fmaf(__builtin_fmaf(-fr.x, r0, Sf), fr.y, r0);
@@ -1719,7 +1729,9 @@ int p2v_launch_avgpool_quant(const int8_t* x, int B, int T, int C, float s_in, f
 
 int p2v_launch_window_attention(const WinAttnArgs& a, hipStream_t st) {
   const int hgroups = (a.H + 3) / 4;
-  hipLaunchKernelGGL(k_window_attention, dim3((unsigned)(a.B * a.wa.n_windows * hgroups)), dim3(256), 0, st, a);
+  const dim3 grid((unsigned)(a.B * a.wa.n_windows * hgroups));
+  if (a.wa.ws == 7) hipLaunchKernelGGL(k_window_attention<49>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_window_attention<0>, grid, dim3(256), 0, st, a);
   CHECK_LAUNCH();
   return 0;
 }
