@@ -178,17 +178,33 @@ def main():
         orc.calib = calib
         nb = 16
         xc = x[:nb].cpu()
+        # torch's intra-op pool is tuned first: at all 128 host threads this restatement runs 9x slower than at 16 on the EPYC
+        # 9575F box (tools/cpu_baseline_threads.py), and a baseline must not be sand-bagged
+        n_host = os.cpu_count() or 1
+        saved = torch.get_num_threads()
+        best_th, best_t = saved, None
         with torch.no_grad():
             orc.quant_forward(xc, bits)
+            for th in [t for t in (8, 16, 32, 64) if t <= n_host] or [saved]:
+                torch.set_num_threads(th)
+                orc.quant_forward(xc, bits)
+                t1 = time.perf_counter()
+                orc.quant_forward(xc, bits)
+                dt1 = time.perf_counter() - t1
+                if best_t is None or dt1 < best_t:
+                    best_th, best_t = th, dt1
+            torch.set_num_threads(best_th)
             t1 = time.perf_counter()
             iters = 0
-            while iters < 2 or (time.perf_counter() - t1 < 10 and iters < 20):
+            while iters < 2 or (time.perf_counter() - t1 < 12 and iters < 200):
                 ref = orc.quant_forward(xc, bits)
                 iters += 1
             tc = time.perf_counter() - t1
+        torch.set_num_threads(saved)
         same = bool(torch.equal(ref, logits[:nb].cpu()))
-        cpu = dict(value=round(nb * iters / tc, 2), unit='images/sec', cores=torch.get_num_threads(), kind='port',
-                   sample='%d forwards of %d images (same weights/bits), oracle/p2vit_oracle.py torch-CPU restatement' % (iters, nb),
+        cpu = dict(value=round(nb * iters / tc, 2), unit='images/sec', cores=best_th, kind='port',
+                   sample='%d forwards of %d images (same weights/bits) in %.0f s, oracle/p2vit_oracle.py torch-CPU restatement, '
+                          'thread count picked from 8/16/32/64 of %d host threads' % (iters, nb, tc, n_host),
                    logits_equal_gpu=same)
 
     if rank == 0:
