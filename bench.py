@@ -86,6 +86,9 @@ def main():
         model = dva.harness.str2model(args.model)(cfg=dva.Config(True, True, 'minmax'))
     model.load_state_dict(sd, strict=False)
     model = model.to(dev).eval()
+    base = dva.synth.images(1000 + rank, min(args.batch, 32), arch['img_size'])
+    with torch.no_grad():                                 # fp32 teacher on the distinct images, before any calibration
+        fp32_top1 = model(base.to(dev))[0].argmax(1).cpu()
     t_cal = time.perf_counter()
     dva.harness.calibrate_model(model, dva.synth.images(SEED, 2, arch['img_size']).to(dev))
     torch.cuda.synchronize()
@@ -101,7 +104,6 @@ def main():
     plan = model.freeze(dev)
     B = args.batch
     # 32 distinct synthetic images per rank, tiled to the batch (content does not change the work)
-    base = dva.synth.images(1000 + rank, min(B, 32), arch['img_size'])
     x = base.repeat((B + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
     bits = [args.bits] * (4 * arch['depth'] + 2)
     logits = torch.empty(B, arch['num_classes'], device=dev)
@@ -131,6 +133,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     value = world * B * args.steps / el
+    top1_fp32 = float((logits[:base.shape[0]].argmax(1).cpu() == fp32_top1).float().mean())   # BASELINE metric: top-1 vs fp32
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, measured live ----------------------
     # One LAUNCH in the timed region covers one batch slice (B / streams images, forward_streams): the profile pass times
@@ -217,6 +220,7 @@ def main():
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'streams_per_gpu': args.streams,
                        'collective': 'all_gather(logits)' if world > 1 else 'none'},
             'roofline': roof,
+            'top1_agreement_fp32': round(top1_fp32, 4),
             'model_mfma_frac': round(model_ops / (el / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
             'kernel_ms_per_step': breakdown,
             'cpu_baseline': cpu,
