@@ -48,6 +48,86 @@ def algorithmic_work(kind, arch, B):
     }[kind]
 
 
+def bench_swin(args, dva, dev, world, rank):
+    """BASELINE config 4 family (parity-test case, not the headline line): Swin through the drop-in surface; the step is
+    SwinPlan.forward (one p2v_run_ops replay per stream slice) + the all-gather of the logits."""
+    import torch.distributed as dist
+    with contextlib.redirect_stdout(sys.stderr):
+        model = dva.harness.str2model(args.model)(cfg=dva.Config(True, True, 'minmax'))
+    model.load_state_dict(dva.synth.swin_state_dict(model.state_dict(), SEED))
+    model = model.to(dev).eval()
+    arch = model.arch
+    base = dva.synth.images(1000 + rank, min(args.batch, 32), arch['img_size'])
+    with torch.no_grad():
+        fp32_top1 = model(base.to(dev)).argmax(1).cpu()
+        t_cal = time.perf_counter()
+        dva.harness.calibrate_model(model, dva.synth.images(SEED, 2, arch['img_size']).to(dev))
+        torch.cuda.synchronize()
+        t_cal = time.perf_counter() - t_cal
+    plan = model.freeze(dev, bits=args.bits)
+    B = args.batch
+    x = base.repeat((B + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
+    gathered = torch.empty(world * B, arch['num_classes'], device=dev) if world > 1 else None
+    out = [None]
+
+    def step():
+        out[0] = plan.forward(x, n_streams=args.streams)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out[0])
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    # roofline of the dominant op kind: one launch = one stream slice, timed by p2v_run_ops_profile (HIP events on the launch stream)
+    n_sl = args.streams if (args.streams > 1 and B >= 16 * args.streams) else 1
+    Bl = (B + n_sl - 1) // n_sl
+    prof = plan.profile(x[:Bl])
+    prof = plan.profile(x[:Bl])
+    rec = plan._recorded[(Bl, 0)]
+    kinds = {}
+    for i, (kind, epi, ms) in enumerate(prof):
+        o = rec['ops'][i]
+        name = kind + ('_' + {0: 'requant', 1: 'gelu', 2: 'resid', 4: 'head'}.get(epi, str(epi)) if kind == 'gemm' else '')
+        ops = 2.0 * o.M * o.K * o.N if kind == 'gemm' else (4.0 * o.i0 * o.i1 * 49 * 32 * o.i2 if kind == 'window_attention' else 0.0)
+        k = kinds.setdefault(name, [0, 0.0, 0.0])
+        k[0] += 1; k[1] += ms; k[2] += ops
+    dom = max(kinds, key=lambda n: kinds[n][1])
+    n_l, ms_l, ops_l = kinds[dom]
+    ach = ops_l / (ms_l * 1e-3) / 1e12
+    roof = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=PEAK_INT8_TOPS, unit='TFLOP/s', frac=round(ach / PEAK_INT8_TOPS, 4),
+                avg_launch_us=round(ms_l / n_l * 1e3, 2), launches_per_step=n_sl * n_l, images_per_launch=Bl, traffic=None)
+    model_ops = n_sl * sum(v[2] for v in kinds.values())
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'images/sec %s (quantized forward)' % args.model, 'value': round(world * B * args.steps / el, 1), 'unit': 'images/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(el / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8' if args.bits == 8 else 'int4w/int8a', 'data': 'synthetic',
+            'config': {'workload': '%s PoT-PTQ forward, int%d weights, %dx%d, batch %d per GPU' % (args.model, args.bits, arch['img_size'], arch['img_size'], B),
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'streams_per_gpu': args.streams,
+                       'collective': 'all_gather(logits)' if world > 1 else 'none'},
+            'roofline': roof,
+            'top1_agreement_fp32': round(float((out[0][:base.shape[0]].argmax(1).cpu() == fp32_top1).float().mean()), 4),
+            'model_mfma_frac': round(model_ops / (el / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
+            'kernel_ms_per_step': {k: round(n_sl * v[1], 3) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1][1])},
+            'cpu_baseline': None, 'calibration': {'seconds': round(t_cal, 2), 'device': 'gpu'},
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -57,7 +137,7 @@ def main():
     ap.add_argument('--bits', type=int, default=8, choices=(4, 8))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--streams', type=int, default=2, help='HIP streams the per-GPU batch is sliced over')
-    ap.add_argument('--model', default=MODEL, choices=('deit_tiny', 'deit_small', 'deit_base', 'vit_base'))
+    ap.add_argument('--model', default=MODEL, choices=('deit_tiny', 'deit_small', 'deit_base', 'vit_base', 'swin_tiny', 'swin_base'))
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for a rehearsal on one GPU)')
     args = ap.parse_args()
 
@@ -77,6 +157,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(args.backend, **({'device_id': dev} if args.backend == 'nccl' else {}))
 
+    if args.model.startswith('swin'):
+        return bench_swin(args, dva, dev, world, rank)
     arch = dva.synth.ARCHS[args.model]
     sd = dva.synth.vit_state_dict(arch, SEED)
     # the reference's flow through the drop-in surface: build, load, calibrate (float pass + observers, on the GPU),
