@@ -105,6 +105,34 @@ def test_deit_small_vs_oracle_and_golden(dva, oracle, synth):
             assert np.array_equal(got, taps[name].reshape(B * T, cols).numpy().astype(np.int64)), (tag, name)
 
 
+def test_deit_small_full_batch_properties(dva, oracle, synth):
+    """BASELINE config 2 at its full size (batch 256): size-independent properties instead of a 256-image CPU oracle run -
+    (a) the 4 oracle-checked images keep their logits at any position of a 256-image batch and in either stream slice,
+    (b) a batch that tiles 32 images repeats its logits with period 32, (c) a ragged batch (255) equals the first 255 rows."""
+    g = load_golden('deit_small')
+    arch = synth.ARCHS['deit_small']
+    seed = int(g['seed'])
+    sd = synth.vit_state_dict(arch, seed)
+    plan = dva.FrozenPlan(arch, sd, golden_calib(g, oracle))
+    bits = [8] * 50
+    x4 = synth.images(seed, int(g['n_eval']), 224, offset=1000)
+    ref4 = plan.forward(x4.cuda(), bits).cpu()                     # == oracle (test_deit_small_vs_oracle_and_golden)
+    base = synth.images(77, 32, 224)
+    base[5:9] = x4
+    x = base.repeat(8, 1, 1, 1).cuda()
+    out = torch.empty(256, 1000, device='cuda')
+    plan.forward_streams(x, bits, out, 2)
+    torch.cuda.synchronize()
+    o = out.cpu()
+    for rep in range(8):
+        assert torch.equal(o[32 * rep: 32 * rep + 32], o[:32]), rep
+        assert torch.equal(o[32 * rep + 5: 32 * rep + 9], ref4), rep
+    one = plan.forward(x, bits).cpu()
+    assert torch.equal(one, o)                                      # one stream == two streams
+    assert torch.equal(plan.forward(x[:255], bits).cpu(), o[:255])
+    assert len(set(o[:32].argmax(1).tolist())) > 3
+
+
 def test_batch_independence_and_ragged_batch(dva, micro):
     """images are independent: a ragged batch (B=5, rows not a multiple of any tile) equals per-image runs."""
     plan = dva.FrozenPlan(micro['arch'], micro['sd'], micro['calib'])
