@@ -8,6 +8,8 @@ returns from ``model(data, bit_config, plot)``, top-k by ``output.topk(maxk, 1, 
 follows the reference.
 """
 import argparse
+import contextlib
+import io
 import os
 import random
 import time
@@ -42,6 +44,10 @@ def build_parser():
     p.add_argument('--synthetic', default=True, action='store_true', help='synthetic ImageNet-shaped data and random-init weights')
     p.add_argument('--n-val', default=500, type=int, help='number of synthetic validation images')
     p.add_argument('--bits', default=8, type=int, choices=[4, 8], help='uniform bit_config for the validation run')
+    p.add_argument('--search-pop', default=25, type=int, help='--mixed: population size (test_quant.py:340)')
+    p.add_argument('--search-iter', default=8, type=int, help='--mixed: evolutionary iterations (test_quant.py:343)')
+    p.add_argument('--search-max-configs', default=50, type=int, help='--mixed: Pareto candidates kept (test_quant.py:281)')
+    p.add_argument('--search-slack', default=1.1, type=float, help='--mixed: size constraint = slack x the all-4-bit model (test_quant.py:262)')
     return p
 
 
@@ -194,7 +200,21 @@ def main(argv=None):
     bit_config = None
     if args.quant:
         print('Calibrating with Gaussian noise...')
-        calibrate_model(model, synth.images(args.seed + 1, args.calib_batchsize, arch['img_size']).to(device))
+        _, FLOPs, global_distance = calibrate_model(model, synth.images(args.seed + 1, args.calib_batchsize, arch['img_size']).to(device))
+        if args.mixed and not _is_swin(model):
+            # test_quant.py:253-408 on the fast path: every candidate bit_config is one validate() over the HIP engine (the frozen
+            # plan holds both weight widths per layer, so switching configurations costs nothing)
+            from .search import mixed_precision_search
+            quiet = argparse.Namespace(**{**vars(args), 'print_freq': 10 ** 9})
+
+            def score(bc):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    return validate(quiet, loader, model, criterion, device, bc)[1]
+            ranked, pop = mixed_precision_search(score, FLOPs, global_distance, seed=args.seed, pop_size=args.search_pop,
+                                                 evo_iter=args.search_iter, max_configs=args.search_max_configs, slack=args.search_slack)
+            print('best mixed-precision configuration: Prec@1 %.3f' % pop[0][1])
+            print(pop[0][0])
+            return validate(args, loader, model, criterion, device, pop[0][0]) + (pop[0][0],)
         bit_config = [args.bits] * ((4 * arch['depth'] + 2) if 'depth' in arch else 1)
         print(bit_config)
     return validate(args, loader, model, criterion, device, bit_config)

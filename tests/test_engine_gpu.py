@@ -370,6 +370,18 @@ def test_harness_main_synthetic(dva, capsys):
     assert 0.0 <= top1 <= 100.0
 
 
+def test_harness_mixed_precision_search_on_the_engine(dva, capsys):
+    """--mixed (test_quant.py:253-408) on the fast path: Pareto sampling + omega ranking + evolutionary search, every candidate a
+    validate() over the HIP engine with its own bit_config; the winner respects the size constraint."""
+    res = dva.harness.main(['--model', 'deit_tiny', '--quant', '--mixed', '--n-val', '16', '--val-batchsize', '16', '--calib-batchsize', '2',
+                            '--search-pop', '4', '--search-iter', '1', '--search-max-configs', '8', '--search-slack', '1.6'])
+    out = capsys.readouterr().out
+    loss, top1, top5, best = res
+    assert 'Pareto Frontier' in out and 'best mixed-precision configuration' in out
+    assert len(best) == 50 and set(best) <= {4, 8} and best[0] == 8
+    assert 0.0 <= top1 <= 100.0
+
+
 # --------------------------------------------------------------------------------------------------
 # other BASELINE configurations as parity cases: DeiT-T (cfg 1 shape), ViT-B int8 (cfg 3), DeiT-B W4 (cfg 5)
 # --------------------------------------------------------------------------------------------------
