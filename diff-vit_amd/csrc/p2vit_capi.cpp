@@ -53,6 +53,7 @@ extern "C" {
 
 extern int g_use_panel;
 extern int g_gemm_waves;
+extern int g_gemm_padlds;
 extern int g_ln_generic;
 extern int g_ln_rows;
 extern int g_attn_waves;
@@ -78,6 +79,8 @@ static void read_env_once() {
   if (e && atoi(e) >= 1 && atoi(e) <= 64) g_ln_rows = atoi(e);
   e = getenv("P2V_LN_GENERIC");
   if (e && atoi(e) == 1) g_ln_generic = 1;
+  e = getenv("P2V_GEMM_PADLDS");
+  if (e) g_gemm_padlds = atoi(e);
   e = getenv("P2V_GEMM_DBG");
   if (e) g_gemm_dbg = atoi(e);
 }

@@ -1502,6 +1502,7 @@ __global__ __launch_bounds__(256) void k_gelu_err_sweep(unsigned first_bits, uns
 // host launchers (called from the C ABI in p2vit_capi.cpp)
 // ---------------------------------------------------------------------------------------------------
 int g_gemm_dbg = 0;
+int g_gemm_padlds = 0;    // P2V_GEMM_PADLDS
 int g_attn_waves = 8;     // P2V_ATTN_WAVES
 unsigned long long* g_gemm_stamps = nullptr;
 int g_gemm_stagger = 0;  // P2V_GEMM_STAGGER=n
@@ -1611,10 +1612,11 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   }
   if (g_gemm_waves == 4 && epi != P2V_EPI_HEAD && epi != P2V_EPI_EMBED) {
     dim3 grid4(g.tiles_n * tiles_m), block4(256);
+    const unsigned pad = (unsigned)g_gemm_padlds;      // P2V_GEMM_PADLDS: dynamic LDS that only limits workgroups per CU (diagnostic)
     switch (epi) {
-      case P2V_EPI_REQUANT: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_REQUANT>, grid4, block4, 0, st, g); break;
-      case P2V_EPI_GELU: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_GELU>, grid4, block4, 0, st, g); break;
-      default: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_RESID>, grid4, block4, 0, st, g); break;
+      case P2V_EPI_REQUANT: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_REQUANT>, grid4, block4, pad, st, g); break;
+      case P2V_EPI_GELU: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_GELU>, grid4, block4, pad, st, g); break;
+      default: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_RESID>, grid4, block4, pad, st, g); break;
     }
     CHECK_LAUNCH();
     return 0;
