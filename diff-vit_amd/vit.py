@@ -369,6 +369,10 @@ class VisionTransformer(nn.Module):
     # ---- frozen integer plan -----------------------------------------------------------------------------------
     def export_calib(self):
         """calibration state in the nested-dict format of ``plan.FrozenPlan`` / ``calib_io``."""
+        if not self.input_quant:
+            raise NotImplementedError('input_quant=False (the reference\'s vit_large factory, vit_fquant.py:925) feeds the fp32 image to the '
+                                      'patch-embed convolution: not an integer pipeline, not part of the fused engine')
+
         def sc(q):
             return q.quantizer.scale.detach().float().cpu()
 
