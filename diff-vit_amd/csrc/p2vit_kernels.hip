@@ -162,23 +162,28 @@ __device__ __forceinline__ void div_q8fx4(const float (&x)[4], const float (&s)[
 // one thread = 4 consecutive pixels of one patch row -> one dword of the patch matrix.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_quantize_patchify(const float* __restrict__ img, int B, int C, int H, int W,
-                                                           int P, float inv_s, int8_t* __restrict__ out, int k_pad) {
+                                                           int P, float inv_s, int8_t* __restrict__ out, int k_pad, int rows_per_block) {
   const int gw = W / P, gh = H / P;
   const int kq = k_pad >> 2;  // dwords per output row
-  const long long total = (long long)B * gh * gw * kq;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    int col = (int)(idx % kq) * 4;
-    long long row = idx / kq;
-    unsigned v = 0;
-    if (col < C * P * P) {
-      int c = col / (P * P), rem = col % (P * P), i = rem / P, j = rem % P;
-      int px = (int)(row % gw), py = (int)((row / gw) % gh), b = (int)(row / ((long long)gw * gh));
-      const float* src = img + (((long long)b * C + c) * H + (py * P + i)) * W + px * P + j;
-      float4 f = *reinterpret_cast<const float4*>(src);
-      v = pack4_sat(rintf(f.x * inv_s), rintf(f.y * inv_s), rintf(f.z * inv_s), rintf(f.w * inv_s));
+  // the (channel, patch row, 4-pixel group) of a thread is fixed: decomposed once, not per element (the per-element 64-bit
+  // div/mod chain of the first version cost ~60 instructions per pixel)
+  const long long rows = (long long)B * gh * gw;
+  for (int d = threadIdx.x; d < kq; d += (int)blockDim.x) {
+    const int col = d * 4;
+    const bool live = col < C * P * P;
+    const int c = col / (P * P), rem = col % (P * P), i = rem / P, j = rem % P;
+    const long long chan_off = ((long long)c * H + i) * W + j;
+    long long row = (long long)blockIdx.x * rows_per_block;
+    const long long row_end = row + rows_per_block < rows ? row + rows_per_block : rows;
+    for (; row < row_end; ++row) {            // row -> (image, patch y, patch x): wave-uniform, scalar arithmetic
+      const int px = (int)(row % gw), py = (int)((row / gw) % gh), b = (int)(row / ((long long)gw * gh));
+      unsigned v = 0;
+      if (live) {
+        const float4 f = *reinterpret_cast<const float4*>(img + (long long)b * C * H * W + chan_off + (long long)py * P * W + px * P);
+        v = pack4_sat(rintf(f.x * inv_s), rintf(f.y * inv_s), rintf(f.z * inv_s), rintf(f.w * inv_s));
+      }
+      *reinterpret_cast<unsigned*>(out + row * k_pad + col) = v;
     }
-    *reinterpret_cast<unsigned*>(out + row * k_pad + col) = v;
   }
 }
 
@@ -1516,11 +1521,10 @@ int g_use_panel = 0;   // P2V_GEMM_PANEL=1 selects the A-stationary panel kernel
   } while (0)
 
 int p2v_launch_patchify(const float* img, int B, int C, int H, int W, int P, float inv_s, int8_t* out, int k_pad, hipStream_t st) {
-  long long total = (long long)B * (H / P) * (W / P) * (k_pad / 4);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_quantize_patchify, dim3(blocks), dim3(256), 0, st, img, B, C, H, W, P, inv_s, out, k_pad);
+  const long long rows = (long long)B * (H / P) * (W / P);
+  const int rows_per_block = 8;
+  hipLaunchKernelGGL(k_quantize_patchify, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st, img, B, C, H, W, P,
+                     inv_s, out, k_pad, rows_per_block);
   CHECK_LAUNCH();
   return 0;
 }
