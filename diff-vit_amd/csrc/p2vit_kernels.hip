@@ -1653,6 +1653,7 @@ int p2v_launch_layernorm(const LnArgs& a_, hipStream_t st) {
     switch (nch) {
       case 5: hipLaunchKernelGGL((k_int_layernorm<5, 64>), grid, block, 0, st, a); break;
       case 6: hipLaunchKernelGGL((k_int_layernorm<6, 64>), grid, block, 0, st, a); break;
+      case 7: hipLaunchKernelGGL((k_int_layernorm<7, 64>), grid, block, 0, st, a); break;
       case 8: hipLaunchKernelGGL((k_int_layernorm<8, 64>), grid, block, 0, st, a); break;
       default: return -1;
     }
@@ -1662,7 +1663,9 @@ int p2v_launch_layernorm(const LnArgs& a_, hipStream_t st) {
       case 2: hipLaunchKernelGGL((k_int_layernorm<2, 32>), grid, block, 0, st, a); break;
       case 3: hipLaunchKernelGGL((k_int_layernorm<3, 32>), grid, block, 0, st, a); break;
       case 4: hipLaunchKernelGGL((k_int_layernorm<4, 32>), grid, block, 0, st, a); break;
+      case 5: hipLaunchKernelGGL((k_int_layernorm<5, 32>), grid, block, 0, st, a); break;
       case 6: hipLaunchKernelGGL((k_int_layernorm<6, 32>), grid, block, 0, st, a); break;
+      case 7: hipLaunchKernelGGL((k_int_layernorm<7, 32>), grid, block, 0, st, a); break;
       case 8: hipLaunchKernelGGL((k_int_layernorm<8, 32>), grid, block, 0, st, a); break;
       default: return -1;
     }

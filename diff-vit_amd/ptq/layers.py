@@ -133,7 +133,8 @@ class QIntLayerNorm(nn.LayerNorm):
         (layers.py:234-238); the exponent is taken exactly (frexp) instead of through log2f."""
         bit = 7
         _, e = torch.frexp(x)
-        N = torch.clamp(bit - (e - 1).to(x.dtype), 0, 31)
+        fl = torch.where(x == 0, torch.full_like(x, float('-inf')), (e - 1).to(x.dtype))     # floor(log2(0)) = -inf -> N = 31
+        N = torch.clamp(bit - fl, 0, 31)
         M = torch.clamp(torch.floor(torch.ldexp(x, N.to(torch.int32))), 0, 2**(bit + 1) - 1)
         return M, N
 

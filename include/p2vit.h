@@ -75,7 +75,9 @@ typedef struct p2v_linear {
  * channel scale and the QAct that follows it (vit_fquant.py:284-289, layers_quant.py:305-311).
  *   x_q = code * mask[c];  mask[c] = round(in_scale[c] / s1), s1 = min_c in_scale[c]
  *   out = clamp(rne(LN_int(x_q) * post_mul[c]), -128, 127)
- * inv_out[c] = 1 / (out_quantizer.scale * out_quantizer_scale[c])  (power of two)
+ * inv_out[c] = 1 / (out_quantizer.scale * out_quantizer_scale[c])  (power of two: the kernel multiplies by it where the
+ *              reference divides by the scale, which is the same fp32 value only for powers of two; with any other value the
+ *              8-bit multiplier M can land one step away when A sits on a dyadic boundary - about 1e-5 of the elements)
  * post_mul[c] = out_scale[c] / next_channel_scale[c] / next_act_scale  (power of two). */
 typedef struct p2v_ln {
   float s1;

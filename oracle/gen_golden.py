@@ -194,10 +194,12 @@ def gen_kat(ref):
         out['lis/%d/codes' % e] = codes.to(torch.int8).numpy()
         out['lis/%d/probs' % e] = p.numpy()
     # QIntLayerNorm.forward mode 'int' with PTF-style input scales, plus get_MN
-    for tag, C, expand in (('a', 96, 1), ('b', 64, 4)):
+    for tag, C, expand in (('a', 96, 1), ('b', 64, 4), ('z', 48, 1)):
         ln = ref_models.QIntLayerNorm(C)
         ln.weight.data = synth.uniform(3, 'kat/ln%s/g' % tag, (C,), -1.5, 1.5)
         ln.bias.data = synth.normal(3, 'kat/ln%s/b' % tag, (C,), 0.3)
+        if tag == 'z':
+            ln.weight.data[::5] = 0.0          # zero multipliers: get_MN(0) -> N = 31, M = 0 (layers.py:234-238)
         ln.mode = 'int'
         nin = C // expand
         base = 0.0123
@@ -218,7 +220,7 @@ def gen_kat(ref):
         out['ln/%s/beta' % tag] = ln.bias.data.numpy()
         out['ln/%s/out' % tag] = y.detach().numpy()
         out['ln/%s/expand' % tag] = np.int64(expand)
-    A = torch.tensor([1e-9, 3e-5, 0.0078125, 0.3, 0.99999994, 1.0, 1.5, 127.9, 128.0, 255.5, 256.0, 1e5])
+    A = torch.tensor([0.0, 1e-9, 3e-5, 0.0078125, 0.3, 0.99999994, 1.0, 1.5, 127.9, 128.0, 255.5, 256.0, 1e5])
     M, N = ln.get_MN(A)
     out['mn/A'], out['mn/M'], out['mn/N'] = A.numpy(), M.numpy(), N.numpy()
     # MinmaxObserver PoT search: activation (layer-wise int8), linear weight (int8 layer / int4 channel)

@@ -193,9 +193,11 @@ def _exp2(n):
 
 
 def _floor_log2(x):
-    """exact binary exponent of |x| > 0."""
+    """exact binary exponent of |x|; -inf for x == 0 like floor(log2(0)) in the reference's get_MN (layers.py:236: a zero
+    multiplier - gamma == 0 - ends with N = 31, M = 0)."""
     _, e = torch.frexp(x)
-    return (e - 1).to(torch.float32)
+    out = (e - 1).to(torch.float32)
+    return torch.where(x == 0, torch.full_like(out, float('-inf')), out)
 
 
 def lis_consts(sf):

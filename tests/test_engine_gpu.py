@@ -656,3 +656,13 @@ def test_swin_batch_independence_and_stream_slices(dva):
         m(torch.zeros(2, 3, 64, 64, device='cuda'))
     with pytest.raises(RuntimeError):
         m._plan.forward(x)                                   # CPU tensor: no fallback
+
+
+def test_fuzz_ops_against_oracle():
+    """tools/fuzz_ops.py: random odd shapes and extreme parameters (zero / tiny / huge gamma, non power-of-two LN output scales,
+    zero-variance rows, all-equal score rows, PTF scales, ...) for LayerNorm, ViT attention and the three GEMM epilogues."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_ops.py'), '3', '12'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '0 failing' in r.stdout

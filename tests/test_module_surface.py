@@ -80,7 +80,7 @@ def test_module_level_ops_against_kats(dva):
         sf = torch.tensor([2.0 ** -e])
         p = sm(torch.from_numpy(g['lis/%d/codes' % e]).float() * sf, sf)
         assert np.array_equal(p.numpy(), g['lis/%d/probs' % e]), e
-    for tag in ('a', 'b'):
+    for tag in ('a', 'b', 'z'):
         C = g['ln/%s/gamma' % tag].shape[0]
         ln = dva.QIntLayerNorm(C)
         ln.weight.data = torch.from_numpy(g['ln/%s/gamma' % tag]); ln.bias.data = torch.from_numpy(g['ln/%s/beta' % tag])

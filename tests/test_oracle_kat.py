@@ -24,7 +24,7 @@ def test_log_int_softmax(oracle):
 
 def test_int_layernorm(oracle):
     g = load_golden('kat_ops')
-    for tag in ('a', 'b'):
+    for tag in ('a', 'b', 'z'):
         ex = int(g['ln/%s/expand' % tag])
         s_in = torch.from_numpy(g['ln/%s/in_scale' % tag])
         if ex != 1:      # in_scale_expand (Swin PatchMerging), layers.py:257-259
@@ -34,7 +34,7 @@ def test_int_layernorm(oracle):
         y = oracle.int_layernorm(codes * s_in.reshape(1, 1, -1), s_in, torch.from_numpy(g['ln/%s/gamma' % tag]),
                                  torch.from_numpy(g['ln/%s/beta' % tag]), out_scale)
         assert np.array_equal((y * out_scale.reshape(1, 1, -1)).numpy(), g['ln/%s/out' % tag]), tag
-        assert np.abs(y.numpy()).max() > 127      # LN output is NOT clamped (layers.py:288-289)
+        assert tag == 'z' or np.abs(y.numpy()).max() > 127      # LN output is NOT clamped (layers.py:288-289)
 
 
 def test_minmax_pot_search(oracle):

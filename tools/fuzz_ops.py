@@ -1,0 +1,154 @@
+"""GPU: randomized parity of the per-operator entry points against the oracle over odd shapes and extreme parameters."""
+import ctypes as C, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import diff_vit_amd as dva
+import p2vit_oracle as O
+E = dva.engine
+L = E.lib()
+g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+fails = 0
+
+
+def rnd(*shape, std=1.0):
+    return torch.randn(*shape, generator=g) * std
+
+
+def ln_case(i):
+    global fails
+    C_ = int(torch.randint(1, 64, (1,), generator=g)) * 4 * int(torch.randint(1, 5, (1,), generator=g))
+    C_ = min(C_, 1024)
+    rows = int(torch.randint(1, 300, (1,), generator=g))
+    codes = torch.clamp(torch.round(rnd(1, rows, C_, std=float(torch.rand(1, generator=g)) * 60 + 1)), -128, 127)
+    if i % 5 == 0:
+        codes[0, 0] = 7                       # zero-variance row: std = 0
+    base = float(2.0 ** torch.randint(-9, 0, (1,), generator=g)) * (1.0 + 0.37 * (i % 3))
+    in_scale = base * 2.0 ** torch.randint(0, 4, (C_,), generator=g).float()
+    gamma = rnd(C_, std=1.0) * (10.0 ** float(torch.randint(-3, 2, (1,), generator=g)))
+    if i % 4 == 1:
+        gamma[::7] = 0.0
+    if i % 4 == 2:
+        gamma[3] = 1e-9
+    beta = rnd(C_, std=0.5) * (100.0 if i % 6 == 3 else 1.0)
+    cs = 2.0 ** torch.randint(-3, 3, (C_,), generator=g).float()
+    s_a = float(2.0 ** torch.randint(-7, -1, (1,), generator=g))
+    out_scale = s_a * cs * (1.0 if i % 7 else 1.3)      # sometimes NOT a power of two: generic chain
+    ln = O.int_layernorm(codes * in_scale.reshape(1, 1, -1), in_scale, gamma, beta, out_scale)
+    ref = torch.clamp(torch.round(ln * 1.0), -128, 127)[0]
+    ref = torch.nan_to_num(ref, nan=0.0)
+    s1 = in_scale.min()
+    dev = [t.contiguous().cuda() for t in (codes[0].to(torch.int8), torch.round(in_scale / s1), gamma, beta, 1.0 / out_scale, torch.ones(C_))]
+    lnp = E.Ln(float(s1), *[E.ptr(t) for t in dev[1:]])
+    out = torch.zeros(rows, C_, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_int_layernorm(E.ptr(dev[0]), C_, rows, C_, C.byref(lnp), E.ptr(out), C_, E.stream_ptr()))
+    got = out.cpu().float()
+    finite = torch.isfinite(ln[0]).all(dim=1)            # rows with std == 0 give inf/nan in the reference: not compared
+    bad = int((got[finite] != ref[finite]).sum())
+    if bad and i % 7 == 0:
+        # non power-of-two output scale: the ABI takes 1/out_scale and multiplies where the reference divides (exact only for
+        # powers of two, the P2-ViT case; include/p2vit.h): a multiplier on a dyadic boundary may land one step away
+        if bad <= max(1, int(1e-4 * got[finite].numel())):       # one 8-bit multiplier off by one step: |diff| <= |x_q| / 2^N + 1
+            bad = 0
+    if bad:
+        fails += 1
+        print('LN case %d C=%d rows=%d: %d mismatches' % (i, C_, rows, bad))
+        idx = ((got != ref) & finite.unsqueeze(1)).nonzero()
+        for r_, c_ in idx[:4].tolist():
+            xq = (codes[0, r_] * torch.round(in_scale / s1)).double()
+            n = C_
+            S1, S2 = xq.sum().float(), (xq * xq).sum().float()
+            std = (s1 / n) * torch.sqrt((n * S2 - S1 * S1).double()).float()
+            A = (s1 / std) * gamma[c_] / out_scale[c_]
+            print('   row %d col %d got %g want %g | ln %.6f gamma %.6g beta %.6g out_scale %.6g A %.6g code %g mask %g' %
+                  (r_, c_, float(got[r_, c_]), float(ref[r_, c_]), float(ln[0, r_, c_]), float(gamma[c_]), float(beta[c_]), float(out_scale[c_]),
+                   float(A), float(codes[0, r_, c_]), float(torch.round(in_scale / s1)[c_])))
+
+
+def attn_case(i):
+    global fails
+    hd = 64 if i % 2 else 32
+    H = int(torch.randint(1, 5, (1,), generator=g))
+    N = [197, 50, 17, 33, 64][i % 5]
+    B = int(torch.randint(1, 4, (1,), generator=g))
+    D = H * hd
+    qkv = torch.clamp(torch.round(rnd(B, N, 3 * D, std=float(torch.rand(1, generator=g)) * 70 + 0.5)), -128, 127)
+    if i % 3 == 0:
+        qkv[0, :, :D] = 0
+    e_q, e_at, e_a2 = int(torch.randint(2, 7, (1,), generator=g)), int(torch.randint(2, 9, (1,), generator=g)), int(torch.randint(1, 6, (1,), generator=g))
+    s_q1, s_at, s_a2 = 2.0 ** -e_q, 2.0 ** -e_at, 2.0 ** -e_a2
+    t = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    acc = t[0] @ t[1].transpose(-2, -1)
+    scale = float(np.float32(hd ** -0.5))
+    sc = torch.clamp(torch.round(((acc * (s_q1 * s_q1)) * scale) / s_at), -128, 127)
+    k = O.lis_int(sc, torch.tensor([s_at]))
+    o = (O.lis_probs(k) @ (t[2] * s_q1)).transpose(1, 2).reshape(B, N, D)
+    ref = torch.clamp(torch.round(o / s_a2), -128, 127)
+    x0, bb, cc = O.lis_consts(torch.tensor([s_at]))
+    at = E.Attn(s_q1 * s_q1, scale, 1.0 / s_at, s_q1 / s_a2, x0, bb, cc)
+    dq = qkv.to(torch.int8).cuda()
+    out = torch.zeros(B * N, D, dtype=torch.int8, device='cuda')
+    pk = torch.full((B, H, N, N), -1, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_lis_attention(E.ptr(dq), B, N, H, hd, C.byref(at), E.ptr(out), E.ptr(pk), E.stream_ptr()))
+    b1, b2 = int((pk.cpu().long() != k).sum()), int((out.cpu().float().reshape(B, N, D) != ref).sum())
+    if b1 or b2:
+        fails += 1
+        print('attention case %d B=%d N=%d H=%d hd=%d s_at=2^-%d: k mismatches %d, out mismatches %d' % (i, B, N, H, hd, e_at, b1, b2))
+
+
+def gemm_case(i):
+    global fails
+    M = int(torch.randint(1, 700, (1,), generator=g))
+    K = 64 * int(torch.randint(1, 25, (1,), generator=g))
+    N = 16 * int(torch.randint(1, 40, (1,), generator=g))
+    x = torch.clamp(torch.round(rnd(M, K, std=50)), -128, 127)
+    w = torch.clamp(torch.round(rnd(N, K, std=40)), -128, 127)
+    bias = rnd(N, std=0.5)
+    s_x = float(2.0 ** torch.randint(-8, -2, (1,), generator=g))
+    s_w = 2.0 ** torch.randint(-10, -4, (N,), generator=g).float()
+    n_pad = (N + 127) // 128 * 128
+    wp = torch.zeros(n_pad, K, dtype=torch.int8); wp[:N] = w.to(torch.int8)
+    cs = torch.zeros(n_pad); cs[:N] = s_x * s_w
+    bp = torch.zeros(n_pad); bp[:N] = bias
+    dev = [t_.cuda() for t_ in (x.to(torch.int8), wp, cs, bp)]
+    lin = E.Linear(E.ptr(dev[1]), E.ptr(dev[2]), E.ptr(dev[3]))
+    y = O.qgemm(x, torch.tensor(s_x), w, s_w, bias)
+    ymax = float(y.abs().max())
+    s_out = float(2.0 ** np.ceil(np.log2(max(ymax, 1e-3) / 100.0)))
+    for kind in (E.EPI_REQUANT, E.EPI_GELU):
+        epi = E.Epilogue(); epi.inv_s_out = 1.0 / s_out
+        out = torch.zeros(M, N, dtype=torch.int8, device='cuda')
+        E.check(L.p2v_gemm_i8(kind, E.ptr(dev[0]), K, M, K, N, C.byref(lin), C.byref(epi), E.ptr(out), N, None, E.stream_ptr()))
+        v = O.gelu_rn(y) if kind == E.EPI_GELU else y
+        ref = torch.clamp(torch.round(v / s_out), -128, 127)
+        bad = int((out.cpu().float() != ref).sum())
+        if bad:
+            fails += 1
+            print('gemm case %d kind %d M=%d K=%d N=%d: %d mismatches' % (i, kind, M, K, N, bad))
+    # residual epilogue with non power-of-two PTF scales
+    res = torch.clamp(torch.round(rnd(M, N, std=50)), -128, 127)
+    s_mid = (0.011 + 0.02 * torch.rand(N, generator=g)) * s_out * 8
+    s_res = (0.013 + 0.02 * torch.rand(N, generator=g)) * 2.0 ** torch.randint(0, 4, (N,), generator=g).float() * s_out * 4
+    s_next = (0.017 + 0.02 * torch.rand(N, generator=g)) * 2.0 ** torch.randint(0, 4, (N,), generator=g).float() * s_out * 4
+    def padv(v):
+        o_ = torch.ones(n_pad); o_[:N] = v; return o_.cuda()
+    dv = [padv(s_mid), padv(s_res), padv(s_next), res.to(torch.int8).cuda()]
+    epi = E.Epilogue()
+    epi.s_mid, epi.s_res, epi.s_next, epi.residual = [E.ptr(t_) for t_ in dv]
+    out = torch.zeros(M, N, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_gemm_i8(E.EPI_RESID, E.ptr(dev[0]), K, M, K, N, C.byref(lin), C.byref(epi), E.ptr(out), N, None, E.stream_ptr()))
+    q3 = torch.clamp(torch.round(y / s_mid), -128, 127)
+    ref = torch.clamp(torch.round((res * s_res + q3 * s_mid) / s_next), -128, 127)
+    bad = int((out.cpu().float() != ref).sum())
+    if bad:
+        fails += 1
+        print('gemm RESID case %d M=%d K=%d N=%d: %d mismatches' % (i, M, K, N, bad))
+
+
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+for i in range(n):
+    ln_case(i)
+    attn_case(i)
+    gemm_case(i)
+torch.cuda.synchronize()
+print('fuzz: %d cases per op, %d failing' % (n, fails))
+sys.exit(1 if fails else 0)
