@@ -660,7 +660,8 @@ def test_swin_batch_independence_and_stream_slices(dva):
 
 def test_fuzz_ops_against_oracle():
     """tools/fuzz_ops.py: random odd shapes and extreme parameters (zero / tiny / huge gamma, non power-of-two LN output scales,
-    zero-variance rows, all-equal score rows, PTF scales, ...) for LayerNorm, ViT attention and the three GEMM epilogues."""
+    zero-variance rows, all-equal score rows, PTF scales, shifted-window masks, ...) for LayerNorm, ViT attention, Swin window attention and
+    the three GEMM epilogues."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_ops.py'), '3', '12'], capture_output=True, text=True, timeout=600)

@@ -144,11 +144,63 @@ def gemm_case(i):
         print('gemm RESID case %d M=%d K=%d N=%d: %d mismatches' % (i, M, K, N, bad))
 
 
+def winattn_case(i):
+    global fails
+    import swin_oracle as SO
+    ws = [7, 4, 8, 7, 2][i % 5]
+    mult = int(torch.randint(1, 4, (1,), generator=g))
+    Hf = ws * mult
+    shift = 0 if (mult == 1 or i % 2 == 0) else int(torch.randint(1, ws, (1,), generator=g))
+    heads = int(torch.randint(1, 9, (1,), generator=g))
+    B = int(torch.randint(1, 4, (1,), generator=g))
+    C_, T, N = heads * 32, Hf * Hf, ws * ws
+    qkv = torch.clamp(torch.round(rnd(B, T, 3 * C_, std=float(torch.rand(1, generator=g)) * 60 + 0.5)), -128, 127)
+    tab = torch.clamp(torch.round(rnd((2 * ws - 1) ** 2, heads, std=40.0)), -128, 127)
+    c = dict(qact1=float(2.0 ** -int(torch.randint(2, 7, (1,), generator=g))), qact_attn1=float(2.0 ** -int(torch.randint(1, 7, (1,), generator=g))),
+             qact_table=float(2.0 ** -int(torch.randint(2, 8, (1,), generator=g))), qact2=float(2.0 ** -int(torch.randint(1, 7, (1,), generator=g))),
+             qact3=float(2.0 ** -int(torch.randint(1, 6, (1,), generator=g))))
+    idx = SO.window_index(Hf, Hf, ws, shift)
+    nW = idx.shape[0]
+    mask = region = None
+    if shift:
+        mask = SO.shifted_window_mask(Hf, Hf, ws, shift)
+        region = dva.swin.shifted_window_regions(Hf, Hf, ws, shift)
+    x0, bb, cc = O.lis_consts(torch.tensor([c['qact2']]))
+    dev = dict(qkv=qkv.to(torch.int8).contiguous().cuda(), tab=tab.to(torch.int8).contiguous().cuda(), idx=idx.to(torch.int32).contiguous().cuda(),
+               reg=None if region is None else region.to(torch.int8).contiguous().cuda())
+    wa = E.WinAttn(c['qact1'], float(np.float32(32 ** -0.5)), c['qact_attn1'], c['qact_table'], c['qact2'], c['qact3'], x0, bb, cc,
+                   E.ptr(dev['tab']), E.ptr(dev['idx']), E.ptr(dev['reg']) if dev['reg'] is not None else None, ws, nW, 0, 0)
+    out = torch.zeros(B * T, C_, dtype=torch.int8, device='cuda')
+    pk = torch.full((B, nW, heads, N, N), -1, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_window_attention(E.ptr(dev['qkv']), B, T, heads, 32, C.byref(wa), E.ptr(out), E.ptr(pk), E.stream_ptr()))
+    xw = qkv[:, idx.reshape(-1)].reshape(B * nW, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    s1 = torch.tensor(c['qact1'])
+    qs = (xw[0] * s1) * torch.tensor(32 ** -0.5, dtype=torch.float32)
+    attn = (qs.double() @ (xw[1] * s1).double().transpose(-2, -1)).float()
+    a1 = SO.q8(attn, c['qact_attn1'])
+    bias = (tab * c['qact_table'])[SO.relative_position_index(ws).reshape(-1)].reshape(N, N, heads).permute(2, 0, 1)
+    a2 = SO.q8(a1 * c['qact_attn1'] + bias.unsqueeze(0), c['qact2'])
+    xi = a2
+    if mask is not None:
+        xi = (a2.reshape(B, nW, heads, N, N) + torch.round(mask / c['qact2']).unsqueeze(1).unsqueeze(0)).reshape(B * nW, heads, N, N)
+    k = O.lis_int(xi, torch.tensor([c['qact2']]))
+    o = (O.lis_probs(k) @ (xw[2] * s1)).transpose(1, 2).reshape(B, nW * N, C_)
+    q3 = SO.q8(o, c['qact3'])
+    want = torch.zeros(B, T, C_)
+    want[:, idx.reshape(-1)] = q3
+    b1 = int((pk.cpu().long().reshape(B * nW, heads, N, N) != k.long()).sum())
+    b2 = int((out.cpu().float().reshape(B, T, C_) != want).sum())
+    if b1 or b2:
+        fails += 1
+        print('window attention case %d ws=%d Hf=%d shift=%d heads=%d B=%d scales %s: k mismatches %d, out mismatches %d' % (i, ws, Hf, shift, heads, B, c, b1, b2))
+
+
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 for i in range(n):
     ln_case(i)
     attn_case(i)
     gemm_case(i)
+    winattn_case(i)
 torch.cuda.synchronize()
 print('fuzz: %d cases per op, %d failing' % (n, fails))
 sys.exit(1 if fails else 0)
