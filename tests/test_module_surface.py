@@ -183,3 +183,22 @@ def test_minus_one_bit_config_error_convention(synth):
         m(x, [-1] + [8] * (L - 1))
     with pytest.raises(ValueError):
         m(x, None)
+
+
+def test_qintlayernorm_module_vs_randomised_reference_vectors():
+    """the drop-in QIntLayerNorm class on tests/golden/kat_fuzz.npz (24 cases from the real reference, see test_oracle_kat.py)."""
+    import diff_vit_amd as dva
+    g = load_golden('kat_fuzz')
+    for i in range(int(g['ln/n'])):
+        p = 'ln/%d/' % i
+        C = g[p + 'gamma'].shape[0]
+        ln = dva.QIntLayerNorm(C)
+        ln.weight.data, ln.bias.data, ln.mode = torch.from_numpy(g[p + 'gamma']), torch.from_numpy(g[p + 'beta']), 'int'
+        class Q: pass                                                   # noqa: E701
+        qi, qo = Q(), Q()
+        qi.scale, qo.scale = torch.from_numpy(g[p + 'in_scale']), torch.from_numpy(g[p + 'out_scale'])
+        ex = int(g[p + 'expand'])
+        full = qi.scale if ex == 1 else qi.scale.unsqueeze(-1).expand(-1, ex).T.reshape(-1)
+        with torch.no_grad():
+            y = ln(torch.from_numpy(g[p + 'codes']).float() * full.reshape(1, 1, -1), qi, qo, None, ex)
+        assert np.array_equal(y.numpy(), g[p + 'out'], equal_nan=True), i

@@ -58,3 +58,25 @@ def test_ptf(oracle):
     assert np.array_equal(s.numpy(), g['ptf/scale'])
     r = s / s.min()
     assert set(np.unique(r.numpy()).tolist()) <= {1.0, 2.0, 4.0, 8.0}
+
+
+def test_randomised_reference_vectors(oracle):
+    """tests/golden/kat_fuzz.npz (oracle/gen_golden_fuzz.py, produced by the REAL reference classes): 24 QIntLayerNorm cases (zero /
+    tiny / huge gamma, PTF scales, non power-of-two output scales, in_scale_expand 4) and 27 QIntSoftmax cases (sf 2^-1..2^-9, -100
+    masks); NaN/inf rows (zero variance) must agree as well."""
+    g = load_golden('kat_fuzz')
+    for i in range(int(g['ln/n'])):
+        p = 'ln/%d/' % i
+        ex = int(g[p + 'expand'])
+        s_in = torch.from_numpy(g[p + 'in_scale'])
+        if ex != 1:
+            s_in = s_in.unsqueeze(-1).expand(-1, ex).T.reshape(-1)
+        codes = torch.from_numpy(g[p + 'codes']).float()
+        out_scale = torch.from_numpy(g[p + 'out_scale'])
+        y = oracle.int_layernorm(codes * s_in.reshape(1, 1, -1), s_in, torch.from_numpy(g[p + 'gamma']), torch.from_numpy(g[p + 'beta']), out_scale)
+        got, want = (y * out_scale.reshape(1, 1, -1)).numpy(), g[p + 'out']
+        assert np.array_equal(got, want, equal_nan=True), (i, int((got != want).sum()))
+    for i in range(int(g['lis/n'])):
+        p = 'lis/%d/' % i
+        k = oracle.lis_int(torch.from_numpy(g[p + 'x_over_sf']).long(), torch.tensor([2.0 ** -int(g[p + 'e'])]))
+        assert np.array_equal(oracle.lis_probs(k).numpy(), g[p + 'probs']), i
