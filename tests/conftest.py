@@ -15,6 +15,11 @@ GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the C-ABI library is a build product (git-ignored): build it once if a fresh checkout has none and hipcc is here
+    so = os.path.join(ROOT, 'diff-vit_amd', 'csrc', 'libp2vit_hip.so')
+    if not os.path.exists(so) and os.path.exists('/opt/rocm/bin/hipcc'):
+        import subprocess
+        subprocess.run(['make', '-C', os.path.dirname(so)], check=True, stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope='session')
