@@ -12,7 +12,6 @@ the format ``export_calib`` produces from the module surface; plus the fp32 ``st
 """
 import ctypes as C
 import weakref
-import math
 
 import numpy as np
 import torch

@@ -84,7 +84,6 @@ class UniformQuantizer(BaseQuantizer):
         scale, zero_point = self._params(None, None)
         if inputs.is_cuda and inputs.dtype == torch.float32 and not bool((zero_point != 0).any()):
             from .. import engine as E       # HIP path: one fused kernel
-            import ctypes as C
             x = inputs.contiguous()
             s = scale.detach().reshape(-1).float().to(x.device).contiguous()
             shape = self.get_reshape_range(x)
