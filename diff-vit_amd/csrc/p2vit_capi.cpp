@@ -5,6 +5,7 @@
 // lists.  p2v_forward walks the graph of VisionTransformer.forward_features/forward
 // (models/vit_fquant.py:700-799) and enqueues 7 kernels per block on the caller's stream.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,6 +31,10 @@ static int launch_rc(int rc, const char* what) {
   return fail(P2V_E_LAUNCH, "%s: %s", what, hipGetErrorString((hipError_t)rc));
 }
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static bool is_pot(float v) {
+  int ex;
+  return v > 0.f && frexpf(v, &ex) == 0.5f;
+}
 
 struct p2v_plan {
   p2v_model_desc d;
@@ -51,44 +56,28 @@ static int bit_index(int bits) { return bits == 4 ? 0 : (bits == 8 ? 1 : -1); }
 
 extern "C" {
 
-extern int g_use_panel;
-extern int g_gemm_waves;
-extern int g_gemm_padlds;
 extern int g_ln_generic;
 extern int g_ln_rows;
 extern int g_attn_waves;
-extern unsigned long long* g_gemm_stamps;
-extern int g_gemm_stagger;
-extern int g_use_resident;
-extern int g_gemm_dbg;
+// Tuning / A-B switches read once per process (first plan or first version query).  None of them changes results:
+// P2V_LN_GENERIC forces the generic LayerNorm chain (bit-identical to the fast one, both are tested).
 static void read_env_once() {
   static bool done = false;
   if (done) return;
   done = true;
-  const char* e = getenv("P2V_GEMM_PANEL");
-  if (e) g_use_panel = (e[0] == '1');
-  e = getenv("P2V_GEMM_RESIDENT");
-  if (e) g_use_resident = atoi(e);
-  e = getenv("P2V_GEMM_WAVES");
-  if (e) g_gemm_waves = atoi(e);
-  e = getenv("P2V_GEMM_STAGGER");
-  if (e) g_gemm_stagger = atoi(e);
-  e = getenv("P2V_ATTN_WAVES");
+  const char* e = getenv("P2V_ATTN_WAVES");
   if (e && atoi(e) >= 4 && atoi(e) <= 8) g_attn_waves = atoi(e);
   e = getenv("P2V_LN_ROWS");
   if (e && atoi(e) >= 1 && atoi(e) <= 64) g_ln_rows = atoi(e);
   e = getenv("P2V_LN_GENERIC");
   if (e && atoi(e) == 1) g_ln_generic = 1;
-  e = getenv("P2V_GEMM_PADLDS");
-  if (e) g_gemm_padlds = atoi(e);
-  e = getenv("P2V_GEMM_DBG");
-  if (e) g_gemm_dbg = atoi(e);
 }
 int p2v_abi_version(void) { read_env_once(); return P2V_ABI_VERSION; }
 const char* p2v_last_error(void) { return g_err; }
 
 int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
   if (!desc || !out) return fail(P2V_E_ARG, "p2v_plan_create: null argument");
+  read_env_once();
   if (desc->abi_version != P2V_ABI_VERSION) return fail(P2V_E_ARG, "ABI version %d != %d", desc->abi_version, P2V_ABI_VERSION);
   const p2v_model_desc& d = *desc;
   if (d.img_size <= 0 || d.patch_size <= 0 || d.img_size % d.patch_size) return fail(P2V_E_SHAPE, "img_size %% patch_size != 0");
@@ -198,7 +187,10 @@ static int run_gemm(int epi, const int8_t* A, int lda, int M, int K, int N, cons
                     int ldo, int8_t* out_codes, hipStream_t st) {
   GemmArgs g;
   g.A = A; g.lda = lda; g.M = M; g.W = lin.w_codes; g.K = K; g.N = N;
-  g.colscale = lin.colscale; g.bias = lin.bias; g.ep = ep; g.out = out; g.ldo = ldo; g.out_codes = out_codes; g.tiles_n = 0; g.dbg = 0; g.stagger = 0; g.stamps = nullptr;
+  g.colscale = lin.colscale; g.bias = lin.bias; g.ep = ep; g.out = out; g.ldo = ldo; g.out_codes = out_codes; g.tiles_n = 0;
+#ifdef P2V_DIAG
+  g.stamps = nullptr;
+#endif
   return launch_rc(p2v_launch_gemm(epi, g, st), "gemm_i8");
 }
 
@@ -277,6 +269,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     // fc1 -> GELU -> qact1                                                  layers_quant.py:316,331-333
     p2v_epilogue e1{};
     e1.inv_s_out = b.inv_s_fc1;
+    e1.gelu = b.gelu_fc1;
     STEP(P2V_K_GEMM_FC1, run_gemm(P2V_EPI_GELU, bufLN, D, M, D, Hd, p->lin[b1][3 + 4 * i], e1, bufHID, Hd, nullptr, st));
     // fc2 -> qact2 -> + x -> Block.qact4                                    layers_quant.py:342-346, vit_fquant.py:468
     p2v_epilogue e2 = b.fc2_epi;
@@ -342,6 +335,9 @@ int p2v_gemm_i8(int kind, const int8_t* A, int lda, int M, int K, int N, const p
   if (M <= 0 || N <= 0 || K <= 0 || K % GBK_PAD) return fail(P2V_E_SHAPE, "K=%d must be a positive multiple of %d", K, GBK_PAD);
   if (kind != P2V_EPI_HEAD && (N % 16 || ldo % 16)) return fail(P2V_E_UNSUPPORTED, "N and ldo must be multiples of 16 for int8 outputs");
   if (lda % 16) return fail(P2V_E_UNSUPPORTED, "lda must be a multiple of 16");
+  if (kind == P2V_EPI_REQUANT && !(is_pot(epi->inv_s_out) && epi->inv_s_out >= 0x1p-40f && epi->inv_s_out <= 0x1p40f))
+    return fail(P2V_E_UNSUPPORTED, "REQUANT: 1/scale %g must be a power of two (it is folded into the column scales)", epi->inv_s_out);
+  if (kind == P2V_EPI_GELU && epi->gelu.table && (epi->gelu.cells <= 0 || epi->gelu.cells > 4096)) return fail(P2V_E_ARG, "GELU table with %d cells", epi->gelu.cells);
   if (kind == P2V_EPI_RESID && (!epi->s_mid || !epi->s_res || !epi->s_next || !epi->residual)) return fail(P2V_E_ARG, "RESID epilogue needs s_mid/s_res/s_next/residual");
   if (kind == P2V_EPI_EMBED && (!epi->s_next || !epi->pos_deq || epi->patches <= 0)) return fail(P2V_E_ARG, "EMBED epilogue needs s_next/pos_deq/patches");
   return run_gemm(kind, A, lda, M, K, N, *lin, *epi, out, ldo, out_codes, (hipStream_t)stream);
@@ -462,8 +458,56 @@ int p2v_gelu_quant_f32(const float* y, long long n, float inv_s, int8_t* codes, 
   return launch_rc(p2v_launch_gelu_quant(y, n, inv_s, codes, flags, force_slow, (hipStream_t)stream), "gelu_quant");
 }
 
-/* debug only (not in the public header): device buffer receiving 6 x uint64 per workgroup of the next tiled GEMM launches */
+#ifdef P2V_DIAG
+/* diagnostic build only (make diag): device buffer receiving 6 x uint64 per workgroup of the next tiled GEMM launches */
+extern unsigned long long* g_gemm_stamps;
 void p2v_debug_set_gemm_stamps(void* dev) { g_gemm_stamps = (unsigned long long*)dev; }
+#endif
+
+int p2v_gelu_table_plan(float inv_s, p2v_gelu_tab* t) {
+  if (!t) return fail(P2V_E_ARG, "p2v_gelu_table_plan: null argument");
+  if (!is_pot(inv_s) || inv_s < 1.0f || inv_s > 4096.0f) return fail(P2V_E_UNSUPPORTED, "gelu table: 1/scale %g is not a power of two in [1, 4096]", inv_s);
+  const double s = 1.0 / (double)inv_s, k = 2.0 * (double)inv_s;          // cells of width s/2
+  // below y_lo every code is 0: |gelu(y)| = 0.5 |y| erfc(|y|/sqrt 2) falls monotonically left of the minimum at -0.7518
+  double y_lo = -0.75;
+  while (y_lo > -40.0 && 0.5 * -y_lo * erfc(-y_lo * 0.70710678118654752440) >= 0.25 * s) y_lo -= 0.5 * s;
+  const long long i0 = (long long)floor((y_lo - s) * k);
+  double y_hi = 127.5 * s;                                                  // gelu(y) < y: the code saturates at 127 a little later
+  while (y_hi < 1.0e4 && 0.5 * y_hi * erfc(-y_hi * 0.70710678118654752440) < 127.75 * s) y_hi += 0.5 * s;
+  const long long i1 = (long long)ceil(y_hi * k) + 2;                       // from here on every code is 127
+  const long long cells = i1 - i0;
+  if (cells > 4096) return fail(P2V_E_UNSUPPORTED, "gelu table: %lld cells for 1/scale %g (limit 4096)", cells, inv_s);
+  t->k = (float)k;
+  t->off = (float)(-i0);
+  t->cells = (int32_t)cells;
+  return P2V_OK;
+}
+
+size_t p2v_gelu_table_scratch_bytes(int cells) { return cells > 0 ? ((size_t)4 * cells + 4) * 4 : 0; }
+
+int p2v_gelu_table_build(float inv_s, const p2v_gelu_tab* t, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!t || !t->table || !scratch) return fail(P2V_E_ARG, "p2v_gelu_table_build: null argument");
+  p2v_gelu_tab want;
+  const int rc = p2v_gelu_table_plan(inv_s, &want);
+  if (rc != P2V_OK) return rc;
+  if (want.k != t->k || want.off != t->off || want.cells != t->cells) return fail(P2V_E_ARG, "p2v_gelu_table_build: descriptor does not come from p2v_gelu_table_plan");
+  if (scratch_bytes < p2v_gelu_table_scratch_bytes(t->cells)) return fail(P2V_E_WORKSPACE, "gelu table scratch %zu < %zu bytes", scratch_bytes, p2v_gelu_table_scratch_bytes(t->cells));
+  hipStream_t st = (hipStream_t)stream;
+  const int lrc = launch_rc(p2v_launch_gelu_table_build(inv_s, *t, (unsigned*)scratch, st), "gelu_table_build");
+  if (lrc != P2V_OK) return lrc;
+  unsigned status = 0;
+  hipError_t e = hipMemcpyAsync(&status, (const unsigned*)scratch + 4 * t->cells, 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return fail(P2V_E_LAUNCH, "gelu_table_build: %s", hipGetErrorString(e));
+  if (status) return fail(P2V_E_UNSUPPORTED, "gelu table for 1/scale %g: %s", inv_s, (status & 1) ? "a cell holds two thresholds" : "a cell is never hit");
+  return P2V_OK;
+}
+
+int p2v_gelu_table_check(float inv_s, const p2v_gelu_tab* t, unsigned long long* mismatches, void* stream) {
+  if (!t || !t->table || !mismatches) return fail(P2V_E_ARG, "p2v_gelu_table_check: null argument");
+  if (t->cells <= 0) return fail(P2V_E_ARG, "p2v_gelu_table_check: empty table");
+  return launch_rc(p2v_launch_gelu_table_check(inv_s, *t, mismatches, (hipStream_t)stream), "gelu_table_check");
+}
 
 int p2v_gelu_err_sweep(unsigned first_bits, unsigned count, float* max_err, void* stream) {
   if (!max_err) return fail(P2V_E_ARG, "p2v_gelu_err_sweep: null argument");

@@ -19,9 +19,9 @@ struct GemmArgs {
   int ldo;
   int8_t* out_codes;
   int tiles_n;          // filled by the launcher
-  int stagger;          // first-round phase stagger in units of 64*127 cycles (0 = off)
-  unsigned long long* stamps;   // debug: per-block s_memtime stamps (5 per block) or null
-  int dbg;              // ablation switches (P2V_GEMM_DBG): 1 skip k-loop, 2 skip epilogue arithmetic, 4 skip stores
+#ifdef P2V_DIAG
+  unsigned long long* stamps;   // diagnostic build only: per-workgroup cycle stamps (6 per workgroup) or null
+#endif
 };
 
 struct LnArgs {
@@ -65,3 +65,6 @@ int p2v_launch_fake_quant(const float* x, long long n, const float* scale, int n
 int p2v_launch_gelu_quant(const float* y, long long n, float inv_s, int8_t* codes, unsigned long long* flags, int force_slow,
                           hipStream_t st);
 int p2v_launch_gelu_sweep(unsigned first_bits, unsigned count, float* max_err, hipStream_t st);
+// exact GELU->requant threshold table (see the GELU section of p2vit_kernels.hip)
+int p2v_launch_gelu_table_build(float inv_s, const p2v_gelu_tab& t, unsigned* scratch, hipStream_t st);
+int p2v_launch_gelu_table_check(float inv_s, const p2v_gelu_tab& t, unsigned long long* mismatches, hipStream_t st);

@@ -124,6 +124,105 @@ __device__ __forceinline__ void gelu_q8x4(const float (&y)[4], float inv_s, floa
   for (int i = 0; i < 4; ++i) q[i] = r[i];          // integral, NOT clamped: the byte packing saturates
 }
 
+// ---------------------------------------------------------------------------------------------------
+// GELU -> PoT requant as an EXACT threshold table (p2v_gelu_tab, include/p2vit.h).
+//   code(y) = clamp(rne(RN32(gelu(y)) * 2^e)) is a step function of the fp32 pre-activation y with < 256 steps.  The y axis is
+//   cut into cells of width s/2 (k = 2/s, a power of two, so y*k is exact):  i = clamp(floor(fma(y, k, off)), 0, cells-1).
+//   Steps of the monotone branch are >= s/1.13 apart, so a cell holds at most ONE step (the builder verifies this for every
+//   cell, also around the minimum of GELU at y = -0.7518 where a down- and an up-step can come close); the entry is
+//   { thr, lo | hi << 8 } and code = y >= thr ? hi : lo  (thr = +inf for a cell without a step).
+//   Epilogue cost per output: fma, med3, cvt, shift, one ds_read_b64, v_cmp, v_cndmask (SDWA: selects the byte AND packs it
+//   into the output dword) -- 6 VALU after the bias fma, against ~22 for the A&S polynomial + margin test.
+//   The table is built on the device by an exhaustive sweep over EVERY finite fp32 in real-line order with the fp64 erfc
+//   (k_gelu_tab_sweep): nothing about monotonicity or step spacing is assumed, it is checked.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned gelu_tab_offset(float y, float k, float off, float tmax) {
+  const float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(y, k, off), 0.f, tmax);    // y*k exact; NaN -> cell 0
+  return (unsigned)t << 3;                                                          // v_cvt_u32_f32 truncates: floor for t >= 0
+}
+__device__ __forceinline__ int gelu_code_exact(float y, float inv_s) {
+  const float r = rintf(gelu_exact(y) * inv_s);
+  return (int)fminf(fmaxf(r, -128.f), 127.f);
+}
+// byte B of d := (y >= thr) ? hi : lo   with e = {thr bits, lo | hi << 8}; the other bytes of d are kept (B > 0) / zeroed (B = 0)
+#define P2V_GELU_SEL(B, UNUSED, DST, YV, ENT)                                                                             \
+  asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:BYTE_" #B " dst_unused:" UNUSED              \
+      " src0_sel:BYTE_0 src1_sel:BYTE_1"                                                                                   \
+      : "+v"(DST) : "v"(YV), "v"(__uint_as_float(ENT.x)), "v"(ENT.y) : "vcc")
+// four outputs of one lane -> one dword of int8 codes
+__device__ __forceinline__ unsigned gelu_tab_q8x4(const float (&y)[4], const unsigned char* tab, float k, float off, float tmax) {
+  uint2 e[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = *reinterpret_cast<const uint2*>(tab + gelu_tab_offset(y[i], k, off, tmax));
+  unsigned d = 0;
+  P2V_GELU_SEL(0, "UNUSED_PAD", d, y[0], e[0]);
+  P2V_GELU_SEL(1, "UNUSED_PRESERVE", d, y[1], e[1]);
+  P2V_GELU_SEL(2, "UNUSED_PRESERVE", d, y[2], e[2]);
+  P2V_GELU_SEL(3, "UNUSED_PRESERVE", d, y[3], e[3]);
+  return d;
+}
+
+// n-th finite fp32 in real-line order: n in [0, 2F), F = 0x7F800000 (negative values by falling magnitude, -0, +0, positives)
+#define P2V_F32_FINITE 0x7F800000ull
+__device__ __forceinline__ float f32_in_order(unsigned long long n) {
+  return __uint_as_float(n < P2V_F32_FINITE ? 0x80000000u | (unsigned)(P2V_F32_FINITE - 1 - n) : (unsigned)(n - P2V_F32_FINITE));
+}
+// scratch: cnt[cells] | thr[cells] | lohi[cells] | first[cells]; first[] preset to 0xFFFFFFFF, cnt[] to 0
+__global__ __launch_bounds__(256) void k_gelu_tab_sweep(float inv_s, float k, float off, float tmax, int cells, unsigned* scratch, int per_thread) {
+  unsigned* cnt = scratch;
+  unsigned* thr = scratch + cells;
+  unsigned* lohi = scratch + 2 * cells;
+  unsigned* first = scratch + 3 * cells;
+  const unsigned long long n0 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * per_thread;
+  if (n0 >= 2 * P2V_F32_FINITE) return;
+  int pc = 0;
+  unsigned pi = 0xFFFFFFFFu;
+  if (n0 > 0) {
+    const float yp = f32_in_order(n0 - 1);
+    pc = gelu_code_exact(yp, inv_s);
+    pi = gelu_tab_offset(yp, k, off, tmax) >> 3;
+  }
+  for (int j = 0; j < per_thread; ++j) {
+    const unsigned long long n = n0 + j;
+    if (n >= 2 * P2V_F32_FINITE) break;
+    const float y = f32_in_order(n);
+    const int c = gelu_code_exact(y, inv_s);
+    const unsigned i = gelu_tab_offset(y, k, off, tmax) >> 3;
+    if (i != pi) first[i] = (unsigned)c & 255u;                 // first value of a cell: its code when the cell has no step
+    if (n > 0 && c != pc) {
+      atomicAdd(&cnt[i], 1u);
+      thr[i] = __float_as_uint(y);
+      lohi[i] = ((unsigned)pc & 255u) | (((unsigned)c & 255u) << 8);
+    }
+    pc = c;
+    pi = i;
+  }
+}
+// status: 0 ok, bit 0 = a cell with two steps, bit 1 = a cell no fp32 value maps to
+__global__ void k_gelu_tab_finish(int cells, const unsigned* scratch, uint2* table, unsigned* status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cells) return;
+  const unsigned c = scratch[i], f = scratch[3 * cells + i];
+  if (c > 1) atomicOr(status, 1u);
+  if (f > 255u) atomicOr(status, 2u);
+  table[i] = c == 0 ? make_uint2(0x7F800000u, f | (f << 8)) : make_uint2(scratch[cells + i], scratch[2 * cells + i]);
+}
+// independent check: every finite fp32 through the epilogue's lookup against the fp64 evaluation
+__global__ __launch_bounds__(256) void k_gelu_tab_check(float inv_s, float k, float off, float tmax, const unsigned char* table,
+                                                        unsigned long long* mismatches) {
+  unsigned long long bad = 0;
+  for (unsigned long long n = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; n < 2 * P2V_F32_FINITE;
+       n += (unsigned long long)gridDim.x * blockDim.x * 4) {
+    float y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = f32_in_order(n + i < 2 * P2V_F32_FINITE ? n + i : n);
+    const unsigned d = gelu_tab_q8x4(y, table, k, off, tmax);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bad += (sx8(d, i) != gelu_code_exact(y[i], inv_s)) ? 1 : 0;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
 // clamp(rne(x / s), -128, 127) with IEEE-division semantics (the reference divides by the non-power-of-two
 // PTF scales, ptf.py:133) at the price of one multiply: t = x * fl(1/s) is within 2^-23 |t| of the true
 // quotient and fl(x/s) within 2^-24 |t|; below |t| = 256 that is < 5e-5, so when t is further than 1e-4 from a
@@ -204,6 +303,7 @@ __global__ void k_fill_cls(int8_t* __restrict__ x, int B, int T, int D, const in
 #define GBM 128
 #define GBN 128
 #define GBK 64
+#define P2V_EPI_GELU_TAB 5   // internal: P2V_EPI_GELU with a threshold table in LDS (p2v_epilogue.gelu.table != NULL)
 
 __device__ __forceinline__ int lds_off64(int row, int chunk) { return row * GBK + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
@@ -216,8 +316,11 @@ template <int EPI>
 __device__ __forceinline__ void gemm_stage_epilogue(EpiLds* e, int n0, int tid, const GemmArgs& g) {
   if (tid < GBN) {
     const int n = n0 + tid;
-    e->colscale[tid] = g.colscale[n];                 // arrays are padded to n_pad
-    e->bias[tid] = g.bias[n];
+    // REQUANT: (acc*cs + b) * 2^e == acc*(cs*2^e) + b*2^e with the same single rounding (power-of-two scaling commutes with
+    // rounding; the plan checks that 1/s_out is a power of two), so the multiply leaves the per-output chain
+    const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : 1.0f;
+    e->colscale[tid] = g.colscale[n] * fold;          // arrays are padded to n_pad
+    e->bias[tid] = g.bias[n] * fold;
     const bool ok = n < g.N;
     if (EPI == P2V_EPI_RESID) {
       const float sm = ok ? g.ep.s_mid[n] : 1.f;
@@ -235,7 +338,7 @@ __device__ __forceinline__ void gemm_stage_epilogue(EpiLds* e, int n0, int tid, 
 
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n_tile, int nl, int h, const GemmArgs& g,
-                                                   const EpiLds* e, uint4 resv) {
+                                                   const EpiLds* e, uint4 resv, const unsigned char* gtab = nullptr) {
   // lane owns output row m, channels n_tile + 8*gq + 4*h + {0..3}, gq = 0..3   (C/D map of 32x32 MFMA);
   // nl = n_tile - n0 (column offset inside the block tile, for the LDS constants)
   const bool row_ok = m < g.M;
@@ -263,9 +366,13 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
     y[2] = __builtin_fmaf((float)acc[4 * gq + 2], cs.z, bs.z);
     y[3] = __builtin_fmaf((float)acc[4 * gq + 3], cs.w, bs.w);
     float q[4];                 // integral floats; the byte packing below saturates to [-128,127]
+    if (EPI == P2V_EPI_GELU_TAB) {
+      d[gq] = gelu_tab_q8x4(y, gtab, g.ep.gelu.k, g.ep.gelu.off, (float)(g.ep.gelu.cells - 1));
+      continue;
+    }
     if (EPI == P2V_EPI_REQUANT) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) q[i] = rintf(y[i] * g.ep.inv_s_out);
+      for (int i = 0; i < 4; ++i) q[i] = rintf(y[i]);          // colscale and bias were pre-multiplied by 2^e (gemm_stage_epilogue)
     } else if (EPI == P2V_EPI_GELU) {
       gelu_q8x4(y, g.ep.inv_s_out, q);
     } else if (EPI == P2V_EPI_RESID) {
@@ -383,7 +490,6 @@ __global__ __launch_bounds__(512, 4) void k_gemm_i8(GemmArgs g) {
   if (nk > 1) G_LOAD(b, 1);
   if (nk > 2) G_LOAD(c, 2);
   gemm_stage_epilogue<EPI>(sE, n0, tid, g);        // visible after the first barrier of the k loop
-  if (g.dbg & 1) __syncthreads();
   uint4 resv[2];                                   // residual codes of this lane's 2 output tiles, requested early
   if (EPI == P2V_EPI_RESID) {
 #pragma unroll
@@ -393,23 +499,13 @@ __global__ __launch_bounds__(512, 4) void k_gemm_i8(GemmArgs g) {
       if (m < g.M && n < g.N) resv[mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
     }
   }
-  for (int kt = 0; kt < ((g.dbg & 1) ? 0 : nk); kt += 3) {
+  for (int kt = 0; kt < nk; kt += 3) {
     G_STEP(a, kt);
     if (kt + 1 < nk) G_STEP(b, kt + 1);
     if (kt + 2 < nk) G_STEP(c, kt + 2);
   }
 #undef G_LOAD
 #undef G_STEP
-  if (g.dbg & 2) {   // ablation: raw accumulator bytes, no fp32 arithmetic
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 32 + 16 * h;
-      uint4 o = make_uint4(acc[mi][0], acc[mi][4], acc[mi][8], acc[mi][12]);
-      if (!(g.dbg & 4) && m < g.M && n < g.N && EPI != P2V_EPI_HEAD)
-        *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)m * g.ldo + n) = o;
-    }
-    return;
-  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
     gemm_epilogue_tile<EPI>(acc[mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 32, wn * 32, h, g, sE,
@@ -439,10 +535,14 @@ __device__ __forceinline__ void gemm_compute_tile_w4(const int8_t* cx, const int
 // Global->LDS staging goes through a 3-deep ring of NAMED registers (an indexed array
 // of prefetch registers is placed in scratch by hipcc: measured, 80 B private segment and a scratch round trip
 // per k-tile): tile t+3 is requested while tile t is computed, one barrier per k-tile.
+#ifdef P2V_DIAG   // make diag: per-workgroup cycle stamps for tools/gemm_timeline.py; never in the product library
 #define P2V_STAMP(slot)                                                                         \
   do {                                                                                          \
     if (g.stamps && threadIdx.x == 0) g.stamps[(long long)blockIdx.x * 6 + (slot)] = __builtin_readcyclecounter(); \
   } while (0)
+#else
+#define P2V_STAMP(slot) do { } while (0)
+#endif
 template <int EPI>
 __global__ __launch_bounds__(256, 3) void k_gemm_i8_w4(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) int8_t lds[2 * (GBM + GBN) * GBK + sizeof(EpiLds)];
@@ -460,13 +560,6 @@ __global__ __launch_bounds__(256, 3) void k_gemm_i8_w4(GemmArgs g) {
   const int tn = t % g.tiles_n, tm = t / g.tiles_n;
   const int m0 = tm * GBM, n0 = tn * GBN;
 
-  // Co-resident workgroups start together and would stay in lock-step (loads, MFMAs and epilogues of all of them
-  // coincide: measured strictly additive phases).  The k-th workgroup placed on a CU in the FIRST round sleeps k thirds
-  // of a tile period, so that later rounds run one block's epilogue under another block's loads/MFMAs.
-  if (g.stagger > 0 && blockIdx.x < 768) {
-    const int phase = (int)(blockIdx.x >> 8);
-    for (int i = 0; i < phase * g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   const int lrow = tid >> 2, lchunk = tid & 3;
   int mr0 = m0 + lrow, mr1 = m0 + lrow + 64;
   mr0 = mr0 < g.M ? mr0 : g.M - 1;
@@ -510,7 +603,10 @@ __global__ __launch_bounds__(256, 3) void k_gemm_i8_w4(GemmArgs g) {
   if (nk > 1) G_LOAD(b, 1);
   if (nk > 2) G_LOAD(c, 2);
   gemm_stage_epilogue<EPI>(sE, n0, tid, g);        // visible after the first barrier of the k loop
-  if (g.dbg & 1) __syncthreads();
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];   // GELU threshold table (cells * 8 bytes)
+  if (EPI == P2V_EPI_GELU_TAB)
+    for (int i = tid; i < g.ep.gelu.cells; i += 256)
+      reinterpret_cast<uint2*>(dyn_lds)[i] = reinterpret_cast<const uint2*>(g.ep.gelu.table)[i];
   uint4 resv[2][2];                                // residual codes of this lane's 4 output tiles, requested early
   if (EPI == P2V_EPI_RESID) {
 #pragma unroll
@@ -523,7 +619,7 @@ __global__ __launch_bounds__(256, 3) void k_gemm_i8_w4(GemmArgs g) {
       }
   }
   P2V_STAMP(1);
-  for (int kt = 0; kt < ((g.dbg & 1) ? 0 : nk); kt += 3) {
+  for (int kt = 0; kt < nk; kt += 3) {
     G_STEP(a, kt);
     if (kt + 1 < nk) G_STEP(b, kt + 1);
     if (kt + 2 < nk) G_STEP(c, kt + 2);
@@ -537,307 +633,11 @@ __global__ __launch_bounds__(256, 3) void k_gemm_i8_w4(GemmArgs g) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
       gemm_epilogue_tile<EPI>(acc[ni][mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, sE,
-                              EPI == P2V_EPI_RESID ? resv[ni][mi] : make_uint4(0, 0, 0, 0));
+                              EPI == P2V_EPI_RESID ? resv[ni][mi] : make_uint4(0, 0, 0, 0), dyn_lds);
   P2V_STAMP(3);
+#ifdef P2V_DIAG
   if (g.stamps && threadIdx.x == 0) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g.stamps[(long long)blockIdx.x * 6 + 4] = xcc; unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g.stamps[(long long)blockIdx.x * 6 + 5] = hw; }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K1b: "panel" GEMM for K <= 384 (qkv, fc1, proj of DeiT-T/S and the micro model).
-//   The activation panel [128 rows][K] is read from HBM once per work item and stays in LDS while the block
-//   walks `tpg` consecutive 128-column weight tiles (from L2).  The next weight tile and its epilogue
-//   constants are requested BEFORE the MFMAs of the current tile and land during its epilogue, which is the
-//   long phase (fp32 requant / GELU: VALU bound), so the block never waits on memory after its prologue.
-//   8 waves (2 per SIMD, so one wave's epilogue VALU overlaps its partner's MFMAs): wave = 64 rows x 32 cols.
-//   LDS: panel KP*128 + 2 weight tiles KP*128 each + 2 constant sets  (149 KB at K = 384) -> one block per CU.
-// ---------------------------------------------------------------------------------------------------
-template <int EPI, int KP>
-__global__ __launch_bounds__(512, 2) void k_gemm_panel(GemmArgs g, int tpg) {
-  constexpr int NKT = KP / GBK;                  // 64-byte k-tiles
-  constexpr int TILE = GBM * GBK;                // bytes of one [128][64] swizzled sub-tile
-  constexpr int NLD = (GBM * KP / 16) / 512;     // uint4 loads per thread for a [128][KP] operand
-  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
-  int8_t* sA = reinterpret_cast<int8_t*>(psm);                         // [NKT][128][64]
-  int8_t* sW = sA + NKT * TILE;                                         // [2][NKT][128][64]
-  EpiLds* sE = reinterpret_cast<EpiLds*>(sW + 2 * NKT * TILE);          // [2]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int groups = (g.tiles_n + tpg - 1) / tpg;
-  int bid = blockIdx.x, nt = gridDim.x, xcd = bid & 7, qd = nt >> 3, rm = nt & 7;
-  const int item = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-  const int mp = item / groups, ng = item % groups;
-  const int m0 = mp * GBM;
-  const int t0 = ng * tpg;
-  const int ntile = (t0 + tpg <= g.tiles_n) ? tpg : g.tiles_n - t0;
-
-  // operand element (row, 16-byte chunk) handled by this thread for load slot i: e = tid + 512*i.
-  // The staging registers are NAMED (w0..w5 / a0..a5): hipcc places an indexed, loop-carried uint4 array in
-  // scratch (measured: 112 B private segment, scratch_store/load per tile).
-#define P2V_FOREACH6(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5)
-#define P2V_ROWCH(i) const int e_ = tid + 512 * (i), row_ = e_ / (KP / 16), ch_ = e_ % (KP / 16)
-  uint4 w0, w1, w2, w3, w4, w5;
-  {
-    uint4 a0, a1, a2, a3, a4, a5;
-#define P2V_LD(i)                                                                                          \
-    if ((i) < NLD) {                                                                                       \
-      P2V_ROWCH(i);                                                                                        \
-      int mr_ = m0 + row_;                                                                                 \
-      mr_ = mr_ < g.M ? mr_ : g.M - 1;                                                                     \
-      a##i = *reinterpret_cast<const uint4*>(g.A + (long long)mr_ * g.lda + ch_ * 16);                     \
-      w##i = *reinterpret_cast<const uint4*>(g.W + (long long)(t0 * GBN + row_) * g.K + ch_ * 16);         \
-    }
-    P2V_FOREACH6(P2V_LD)
-#undef P2V_LD
-#define P2V_ST(i)                                                                                          \
-    if ((i) < NLD) {                                                                                       \
-      P2V_ROWCH(i);                                                                                        \
-      const int off_ = (ch_ >> 2) * TILE + lds_off64(row_, ch_ & 3);                                       \
-      *reinterpret_cast<uint4*>(sA + off_) = a##i;                                                         \
-      *reinterpret_cast<uint4*>(sW + off_) = w##i;                                                         \
-    }
-    P2V_FOREACH6(P2V_ST)
-#undef P2V_ST
-  }
-  gemm_stage_epilogue<EPI>(&sE[0], t0 * GBN, tid, g);
-  __syncthreads();
-
-  for (int j = 0; j < ntile; ++j) {
-    const int n0 = (t0 + j) * GBN;
-    const bool more = j + 1 < ntile;
-    {
-      // unconditional (the last step re-reads its own tile from L2): a conditional refill of a loop-carried
-      // register array is placed in scratch by hipcc
-      const int nn = more ? n0 + GBN : n0;
-#define P2V_LW(i)                                                                                          \
-      if ((i) < NLD) {                                                                                     \
-        P2V_ROWCH(i);                                                                                      \
-        w##i = *reinterpret_cast<const uint4*>(g.W + (long long)(nn + row_) * g.K + ch_ * 16);             \
-      }
-      P2V_FOREACH6(P2V_LW)
-#undef P2V_LW
-    }
-    uint4 resv[2];
-    if (EPI == P2V_EPI_RESID) {
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 32 + 16 * h;
-        resv[mi] = make_uint4(0, 0, 0, 0);
-        if (m < g.M && n < g.N) resv[mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
-      }
-    }
-    v16i acc[2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][r] = 0;
-    const int8_t* cw = sW + (j & 1) * NKT * TILE;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const v4i fw = *reinterpret_cast<const v4i*>(cw + kt * TILE + lds_off64(wn * 32 + l31, 2 * ks + h));
-        const v4i f0 = *reinterpret_cast<const v4i*>(sA + kt * TILE + lds_off64(wm * 64 + l31, 2 * ks + h));
-        const v4i f1 = *reinterpret_cast<const v4i*>(sA + kt * TILE + lds_off64(wm * 64 + 32 + l31, 2 * ks + h));
-        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw, f0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw, f1, acc[1], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-      gemm_epilogue_tile<EPI>(acc[mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 32, wn * 32, h, g, &sE[j & 1],
-                              EPI == P2V_EPI_RESID ? resv[mi] : make_uint4(0, 0, 0, 0));
-    if (more) {
-      int8_t* nw = sW + ((j + 1) & 1) * NKT * TILE;     // last read two steps ago, behind the previous barrier
-#define P2V_SW(i)                                                                                          \
-      if ((i) < NLD) {                                                                                     \
-        P2V_ROWCH(i);                                                                                      \
-        *reinterpret_cast<uint4*>(nw + (ch_ >> 2) * TILE + lds_off64(row_, ch_ & 3)) = w##i;               \
-      }
-      P2V_FOREACH6(P2V_SW)
-#undef P2V_SW
-      gemm_stage_epilogue<EPI>(&sE[(j + 1) & 1], n0 + GBN, tid, g);
-    }
-    __syncthreads();
-  }
-#undef P2V_FOREACH6
-#undef P2V_ROWCH
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K1c: persistent "resident" GEMM for K = 384 (qkv, fc1, proj of DeiT-S).
-//   Measured on the tiled kernel: time = (launch + first loads + stores) + k-loop + epilogue, strictly additive
-//   -- co-resident workgroups start together and stay in lock-step, so one block's loads never overlap another
-//   block's arithmetic.  Here the overlap is explicit: a block owns a contiguous range of 256x128 output tiles
-//   (n fastest, so the 256-row activation panel is reused from LDS across the n-tiles of a row panel), keeps
-//   BOTH whole-K operands of a tile in LDS (144 KB), and requests the operands of tile t+1 in four slices
-//   that ride under the four epilogue sub-tiles of tile t (the epilogue is the long, VALU-bound phase).
-//   8 waves (2 per SIMD), wave tile 64x64, one workgroup per CU, grid = #CUs.
-// ---------------------------------------------------------------------------------------------------
-// ---- epilogue of the resident kernel -----------------------------------------------------------------------------------
-// Same arithmetic as gemm_epilogue_tile.  Two differences that only matter while an LDS-DMA is in flight:
-//  * the per-channel constants are read from LDS with inline-asm ds_read_b128: hipcc inserts s_waitcnt vmcnt(0) in front
-//    of any LDS access it can see while a global_load_lds is pending (it cannot prove the constants do not alias the DMA
-//    destination), which would serialise the prefetch behind the epilogue (seen in the ISA);
-//  * the packed result is RETURNED, not stored: the caller stores it after the barrier that retires the DMA, so that the
-//    barrier's vmcnt(0) never waits for this tile's own output stores (vmcnt counts stores on CDNA).
-struct EpiRegs { float4 cs, bs, sm, sr, sn, rm, rn; };
-template <int EPI>
-__device__ __forceinline__ EpiRegs lds_epi_consts(const EpiLds* e, int c) {
-  EpiRegs r;
-  const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)(e->colscale + c);
-  if (EPI == P2V_EPI_RESID) {
-    asm volatile(
-        "ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:512\n\tds_read_b128 %2, %7 offset:1024\n\tds_read_b128 %3, %7 offset:1536\n\t"
-        "ds_read_b128 %4, %7 offset:2048\n\tds_read_b128 %5, %7 offset:2560\n\tds_read_b128 %6, %7 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-        : "=&v"(r.cs), "=&v"(r.bs), "=&v"(r.sm), "=&v"(r.sr), "=&v"(r.sn), "=&v"(r.rm), "=&v"(r.rn)
-        : "v"(a));
-  } else {
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r.cs), "=&v"(r.bs) : "v"(a));
-  }
-  return r;
-}
-
-template <int EPI>
-__device__ __forceinline__ uint4 gemm_epilogue_tile_res(const v16i& acc, int nl, int h, const GemmArgs& g, const EpiLds* e, uint4 resv) {
-  unsigned d[4], res[4];
-  if (EPI == P2V_EPI_RESID) row16_to_halves(resv, res[0], res[1], res[2], res[3]);
-#pragma unroll
-  for (int gq = 0; gq < 4; ++gq) {
-    const EpiRegs k = lds_epi_consts<EPI>(e, nl + 8 * gq + 4 * h);
-    float y[4];
-    y[0] = __builtin_fmaf((float)acc[4 * gq + 0], k.cs.x, k.bs.x);   // exact product: one rounding (see gemm_epilogue_tile)
-    y[1] = __builtin_fmaf((float)acc[4 * gq + 1], k.cs.y, k.bs.y);
-    y[2] = __builtin_fmaf((float)acc[4 * gq + 2], k.cs.z, k.bs.z);
-    y[3] = __builtin_fmaf((float)acc[4 * gq + 3], k.cs.w, k.bs.w);
-    float q[4];
-    if (EPI == P2V_EPI_REQUANT) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) q[i] = rintf(y[i] * g.ep.inv_s_out);
-    } else if (EPI == P2V_EPI_GELU) {
-      gelu_q8x4(y, g.ep.inv_s_out, q);
-    } else {
-      const float smv[4] = {k.sm.x, k.sm.y, k.sm.z, k.sm.w}, srv[4] = {k.sr.x, k.sr.y, k.sr.z, k.sr.w};
-      const float snv[4] = {k.sn.x, k.sn.y, k.sn.z, k.sn.w}, rmv[4] = {k.rm.x, k.rm.y, k.rm.z, k.rm.w}, rnv[4] = {k.rn.x, k.rn.y, k.rn.z, k.rn.w};
-      float q3[4], xs[4];
-      div_q8fx4<true>(y, smv, rmv, q3);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xs[i] = (float)sx8(res[gq], i) * srv[i] + q3[i] * smv[i];
-      div_q8fx4<false>(xs, snv, rnv, q);
-    }
-    d[gq] = pack4_sat(q[0], q[1], q[2], q[3]);
-    if (EPI == P2V_EPI_RESID) __builtin_amdgcn_sched_barrier(0);
-  }
-  return halves_to_row16(d[0], d[1], d[2], d[3]);
-}
-
-#define RBM 256
-// 16 waves (4 per SIMD: the fp32 epilogue chains issue at ~2.1 cycles/instruction only with >= 4 waves per SIMD, measured),
-// 4 (m) x 4 (n) waves of 64 x 32 outputs, <= 128 VGPRs.
-template <int EPI>
-__global__ __launch_bounds__(1024, 4) void k_gemm_resident(GemmArgs g, int tiles_total, int tiles_per_block) {
-  constexpr int KP = 384, NKT = KP / GBK;                      // k-tiles
-  constexpr int ATILE = RBM * GBK, WTILE = GBN * GBK;
-  extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
-  int8_t* sA = reinterpret_cast<int8_t*>(rsm);                 // [NKT][256][64] swizzled
-  int8_t* sW = sA + NKT * ATILE;                                // [NKT][128][64] swizzled
-  EpiLds* sE = reinterpret_cast<EpiLds*>(sW + NKT * WTILE);     // [2]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int t_begin = blockIdx.x * tiles_per_block;
-  int t_end = t_begin + tiles_per_block;
-  t_end = t_end < tiles_total ? t_end : tiles_total;
-  if (t_begin >= t_end) return;
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int lr = lane >> 2, pc = lane & 3;
-
-  // LDS-DMA of a whole-K operand: a wave-instruction writes 64 x 16 B linearly = 16 rows of a [rows][64] sub-tile, so the
-  // XOR swizzle goes on the per-lane SOURCE address: slot (row, pc) receives logical chunk pc ^ ((row>>2)&3).
-  auto dma_A = [&](int mp_) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int jj = wv + 16 * i, rb = jj & 15, kt = jj >> 4;
-      const int row = rb * 16 + lr;
-      int mr = mp_ * RBM + row;
-      mr = mr < g.M ? mr : g.M - 1;
-      const int8_t* src = g.A + (long long)mr * g.lda + kt * GBK + ((pc ^ ((row >> 2) & 3)) << 4);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sA + kt * ATILE + rb * 16 * GBK), 16, 0, 0);
-    }
-  };
-  auto dma_W = [&](int tn_) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int jj = wv + 16 * i, rb = jj & 7, kt = jj >> 3;
-      const int row = rb * 16 + lr;
-      const int8_t* src = g.W + (long long)(tn_ * GBN + row) * g.K + kt * GBK + ((pc ^ ((row >> 2) & 3)) << 4);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sW + kt * WTILE + rb * 16 * GBK), 16, 0, 0);
-    }
-  };
-  dma_A(t_begin / g.tiles_n);
-  dma_W(t_begin % g.tiles_n);
-  gemm_stage_epilogue<EPI>(&sE[0], (t_begin % g.tiles_n) * GBN, tid, g);
-  __syncthreads();          // carries the vmcnt(0) that retires the LDS-DMA
-
-  for (int t = t_begin, it = 0; t < t_end; ++t, ++it) {
-    const int mp = t / g.tiles_n, tn = t % g.tiles_n;
-    const int m0 = mp * RBM, n0 = tn * GBN;
-    const bool more = t + 1 < t_end;
-    const int mp2 = more ? (t + 1) / g.tiles_n : mp, tn2 = more ? (t + 1) % g.tiles_n : tn;
-    uint4 resv[2];
-    if (EPI == P2V_EPI_RESID) {
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 32 + 16 * h;
-        resv[mi] = make_uint4(0, 0, 0, 0);
-        if (m < g.M && n < g.N) resv[mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
-      }
-    }
-    if (g.stamps && tid == 0 && it < 8) g.stamps[((long long)blockIdx.x * 8 + it) * 4 + 0] = __builtin_readcyclecounter();
-    v16i acc[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][r] = 0;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const v4i fw = *reinterpret_cast<const v4i*>(sW + kt * WTILE + lds_off64(wn * 32 + l31, 2 * ks + h));
-        const v4i f0 = *reinterpret_cast<const v4i*>(sA + kt * ATILE + lds_off64(wm * 64 + l31, 2 * ks + h));
-        const v4i f1 = *reinterpret_cast<const v4i*>(sA + kt * ATILE + lds_off64(wm * 64 + 32 + l31, 2 * ks + h));
-        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw, f0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw, f1, acc[1], 0, 0, 0);
-      }
-    }
-    // every wave has read its fragments -> the operand buffers may be overwritten.  Raw barrier: only the LDS reads have
-    // to be complete (lgkmcnt); a __syncthreads() here would also wait for the previous tile's output stores.
-    if (g.stamps && tid == 0 && it < 8) g.stamps[((long long)blockIdx.x * 8 + it) * 4 + 1] = __builtin_readcyclecounter();
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (more) {     // operands of tile t+1 fly under the whole epilogue of tile t
-      if (mp2 != mp) dma_A(mp2);
-      dma_W(tn2);
-    }
-    uint4 o0 = gemm_epilogue_tile_res<EPI>(acc[0], wn * 32, h, g, &sE[it & 1], EPI == P2V_EPI_RESID ? resv[0] : make_uint4(0, 0, 0, 0));
-    uint4 o1 = gemm_epilogue_tile_res<EPI>(acc[1], wn * 32, h, g, &sE[it & 1], EPI == P2V_EPI_RESID ? resv[1] : make_uint4(0, 0, 0, 0));
-    if (g.stamps && tid == 0 && it < 8) g.stamps[((long long)blockIdx.x * 8 + it) * 4 + 2] = __builtin_readcyclecounter();
-    if (g.stamps && lane == 0 && it < 8 && blockIdx.x < 16) g.stamps[8192 + ((long long)blockIdx.x * 8 + it) * 32 + wave] = __builtin_readcyclecounter();
-    if (more) gemm_stage_epilogue<EPI>(&sE[(it + 1) & 1], tn2 * GBN, tid, g);
-    // DMA landed + next constants written; the outstanding VMEM ops at this point are the DMA (issued an epilogue ago) and
-    // the previous tile's stores (issued a whole tile ago)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (g.stamps && lane == 0 && it < 8 && blockIdx.x < 16) g.stamps[8192 + ((long long)blockIdx.x * 8 + it) * 32 + 16 + wave] = __builtin_readcyclecounter();
-    asm volatile("s_barrier" ::: "memory");
-    if (g.stamps && tid == 0 && it < 8) g.stamps[((long long)blockIdx.x * 8 + it) * 4 + 3] = __builtin_readcyclecounter();
-    {
-      const int n = n0 + wn * 32 + 16 * h;
-      const int ma = m0 + wm * 64 + l31, mb = ma + 32;
-      if (ma < g.M && n < g.N) *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)ma * g.ldo + n) = o0;
-      if (mb < g.M && n < g.N) *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)mb * g.ldo + n) = o1;
-    }
-  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1506,14 +1306,10 @@ __global__ __launch_bounds__(256) void k_gelu_err_sweep(unsigned first_bits, uns
 // ---------------------------------------------------------------------------------------------------
 // host launchers (called from the C ABI in p2vit_capi.cpp)
 // ---------------------------------------------------------------------------------------------------
-int g_gemm_dbg = 0;
-int g_gemm_padlds = 0;    // P2V_GEMM_PADLDS
 int g_attn_waves = 8;     // P2V_ATTN_WAVES
+#ifdef P2V_DIAG
 unsigned long long* g_gemm_stamps = nullptr;
-int g_gemm_stagger = 0;  // P2V_GEMM_STAGGER=n
-int g_gemm_waves = 4;     // P2V_GEMM_WAVES=8: 8-wave (64x32 wave tile, <=128 VGPR) shape of the tiled kernel
-int g_use_resident = 0;   // P2V_GEMM_RESIDENT=0: tiled kernel everywhere (A/B runs)
-int g_use_panel = 0;   // P2V_GEMM_PANEL=1 selects the A-stationary panel kernel for K<=384 (A/B runs; measured slower: 1 block/CU)
+#endif
 #define CHECK_LAUNCH()                                     \
   do {                                                     \
     hipError_t e_ = hipGetLastError();                     \
@@ -1535,105 +1331,33 @@ int p2v_launch_fill_cls(int8_t* x, int B, int T, int D, const int8_t* cls, hipSt
   return 0;
 }
 
-template <int EPI, int KP>
-static int launch_panel_t(const GemmArgs& g, int tiles_m, hipStream_t st) {
-  constexpr size_t smem = (size_t)3 * GBM * KP + 2 * sizeof(EpiLds);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_panel<EPI, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  // tiles per work item: keep >= ~4 items per CU so the last round is well filled
-  int tpg = (int)(((long long)g.tiles_n * tiles_m) / 1024);
-  tpg = tpg < 1 ? 1 : (tpg > g.tiles_n ? g.tiles_n : tpg);
-  if (tpg > 4) tpg = 4;
-  const int groups = (g.tiles_n + tpg - 1) / tpg;
-  hipLaunchKernelGGL((k_gemm_panel<EPI, KP>), dim3(groups * tiles_m), dim3(512), smem, st, g, tpg);
-  CHECK_LAUNCH();
-  return 0;
-}
-
-template <int EPI>
-static int launch_panel(const GemmArgs& g, int tiles_m, hipStream_t st) {
-  switch (g.K) {
-    case 64: return launch_panel_t<EPI, 64>(g, tiles_m, st);
-    case 192: return launch_panel_t<EPI, 192>(g, tiles_m, st);
-    case 256: return launch_panel_t<EPI, 256>(g, tiles_m, st);
-    case 384: return launch_panel_t<EPI, 384>(g, tiles_m, st);
-    default: return -2;
-  }
-}
-
-template <int EPI>
-static int launch_resident(const GemmArgs& g, hipStream_t st) {
-  constexpr size_t smem = (size_t)(RBM + GBN) * 384 + 2 * sizeof(EpiLds);
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_resident<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorUnknown;
-    n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
-  const int tiles_total = g.tiles_n * ((g.M + RBM - 1) / RBM);
-  int blocks = n_cu < tiles_total ? n_cu : tiles_total;
-  const int tpb = (tiles_total + blocks - 1) / blocks;
-  blocks = (tiles_total + tpb - 1) / tpb;
-  hipLaunchKernelGGL((k_gemm_resident<EPI>), dim3(blocks), dim3(1024), smem, st, g, tiles_total, tpb);
-  CHECK_LAUNCH();
-  return 0;
-}
-
 int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   GemmArgs g = g0;
-  g.dbg = g_gemm_dbg;
-  g.stagger = g_gemm_stagger;
+#ifdef P2V_DIAG
   g.stamps = g_gemm_stamps;
+#endif
   g.tiles_n = (g.N + GBN - 1) / GBN;
   const int tiles_m = (g.M + GBM - 1) / GBM;
-  // resident kernel: K == 384, enough tiles to give every CU a few (else the tiled kernel's finer grain wins)
-  if (g_use_resident && g.K == 384 && g.lda == 384 && (long long)g.tiles_n * ((g.M + RBM - 1) / RBM) >= 512 && g.N % GBN == 0) {
-    switch (epi) {
-      case P2V_EPI_REQUANT: return launch_resident<P2V_EPI_REQUANT>(g, st);
-      case P2V_EPI_GELU: return launch_resident<P2V_EPI_GELU>(g, st);
-      case P2V_EPI_RESID: if (g_use_resident != 3) return launch_resident<P2V_EPI_RESID>(g, st); break;
-      default: break;
-    }
-  }
-  if (g_use_panel && (g.K == 64 || g.K == 192 || g.K == 256 || g.K == 384) && g.lda == g.K) {
-    int rc = -2;
-    switch (epi) {
-      case P2V_EPI_REQUANT: rc = launch_panel<P2V_EPI_REQUANT>(g, tiles_m, st); break;
-      case P2V_EPI_GELU: rc = launch_panel<P2V_EPI_GELU>(g, tiles_m, st); break;
-      case P2V_EPI_RESID: rc = launch_panel<P2V_EPI_RESID>(g, tiles_m, st); break;
-      default: break;
-    }
-    if (rc != -2) return rc;
-  }
-  if (g_gemm_waves == 4 && epi != P2V_EPI_HEAD && epi != P2V_EPI_EMBED) {
+  if (epi != P2V_EPI_HEAD && epi != P2V_EPI_EMBED) {
     dim3 grid4(g.tiles_n * tiles_m), block4(256);
-    const unsigned pad = (unsigned)g_gemm_padlds;      // P2V_GEMM_PADLDS: dynamic LDS that only limits workgroups per CU (diagnostic)
     switch (epi) {
-      case P2V_EPI_REQUANT: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_REQUANT>, grid4, block4, pad, st, g); break;
-      case P2V_EPI_GELU: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_GELU>, grid4, block4, pad, st, g); break;
-      default: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_RESID>, grid4, block4, pad, st, g); break;
+      case P2V_EPI_REQUANT: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_REQUANT>, grid4, block4, 0, st, g); break;
+      case P2V_EPI_GELU:
+        if (g.ep.gelu.table)
+          hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_GELU_TAB>, grid4, block4, (unsigned)g.ep.gelu.cells * 8u, st, g);
+        else
+          hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_GELU>, grid4, block4, 0, st, g);
+        break;
+      case P2V_EPI_RESID: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_RESID>, grid4, block4, 0, st, g); break;
+      default: return -1;
     }
     CHECK_LAUNCH();
     return 0;
   }
+  // EMBED / HEAD: one launch each per forward; 8-wave shape (64x32 wave tiles, <= 128 VGPRs)
   dim3 grid(g.tiles_n * tiles_m), block(512);
-  switch (epi) {
-    case P2V_EPI_REQUANT: hipLaunchKernelGGL(k_gemm_i8<P2V_EPI_REQUANT>, grid, block, 0, st, g); break;
-    case P2V_EPI_GELU: hipLaunchKernelGGL(k_gemm_i8<P2V_EPI_GELU>, grid, block, 0, st, g); break;
-    case P2V_EPI_RESID: hipLaunchKernelGGL(k_gemm_i8<P2V_EPI_RESID>, grid, block, 0, st, g); break;
-    case P2V_EPI_EMBED: hipLaunchKernelGGL(k_gemm_i8<P2V_EPI_EMBED>, grid, block, 0, st, g); break;
-    case P2V_EPI_HEAD: hipLaunchKernelGGL(k_gemm_i8<P2V_EPI_HEAD>, grid, block, 0, st, g); break;
-    default: return -1;
-  }
+  if (epi == P2V_EPI_EMBED) hipLaunchKernelGGL(k_gemm_i8<P2V_EPI_EMBED>, grid, block, 0, st, g);
+  else hipLaunchKernelGGL(k_gemm_i8<P2V_EPI_HEAD>, grid, block, 0, st, g);
   CHECK_LAUNCH();
   return 0;
 }
@@ -1793,6 +1517,31 @@ int p2v_launch_gelu_quant(const float* y, long long n, float inv_s, int8_t* code
 
 int p2v_launch_gelu_sweep(unsigned first_bits, unsigned count, float* max_err, hipStream_t st) {
   hipLaunchKernelGGL(k_gelu_err_sweep, dim3(2048), dim3(256), 0, st, first_bits, count, max_err);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int p2v_launch_gelu_table_build(float inv_s, const p2v_gelu_tab& t, unsigned* scratch, hipStream_t st) {
+  const int cells = t.cells;
+  // scratch: cnt | thr | lohi | first | status
+  hipError_t e = hipMemsetAsync(scratch, 0, (size_t)3 * cells * 4, st);
+  if (e == hipSuccess) e = hipMemsetAsync(scratch + 3 * cells, 0xFF, (size_t)cells * 4, st);
+  if (e == hipSuccess) e = hipMemsetAsync(scratch + 4 * cells, 0, 4, st);
+  if (e != hipSuccess) return (int)e;
+  const int per_thread = 2048;
+  const unsigned long long threads = (2 * P2V_F32_FINITE + per_thread - 1) / per_thread;
+  hipLaunchKernelGGL(k_gelu_tab_sweep, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, inv_s, t.k, t.off, (float)(cells - 1), cells,
+                     scratch, per_thread);
+  CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_gelu_tab_finish, dim3((cells + 255) / 256), dim3(256), 0, st, cells, scratch,
+                     reinterpret_cast<uint2*>(const_cast<void*>(t.table)), scratch + 4 * cells);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int p2v_launch_gelu_table_check(float inv_s, const p2v_gelu_tab& t, unsigned long long* mismatches, hipStream_t st) {
+  hipLaunchKernelGGL(k_gelu_tab_check, dim3(8192), dim3(256), 0, st, inv_s, t.k, t.off, (float)(t.cells - 1),
+                     reinterpret_cast<const unsigned char*>(t.table), mismatches);
   CHECK_LAUNCH();
   return 0;
 }

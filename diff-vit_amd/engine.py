@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libp2vit_hip.so')
 
-P2V_ABI_VERSION = 1
+P2V_ABI_VERSION = 2
 EPI_REQUANT, EPI_GELU, EPI_RESID, EPI_EMBED, EPI_HEAD = 0, 1, 2, 3, 4
 E_ARG, E_BITS, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH, E_STATE = -1, -2, -3, -4, -5, -6, -7
 
@@ -43,14 +43,19 @@ class WinAttn(C.Structure):
                 ('b_int', _i), ('c_int', _i), ('table_codes', _p), ('win_index', _p), ('region', _p), ('ws', _i), ('n_windows', _i), ('qkv_stride', _i), ('out_stride', _i)]
 
 
+class GeluTab(C.Structure):
+    """exact GELU -> requant threshold table (``p2v_gelu_tab``); ``table`` None = arithmetic evaluation."""
+    _fields_ = [('table', _p), ('k', _f), ('off', _f), ('cells', _i)]
+
+
 class Epilogue(C.Structure):
     _fields_ = [('inv_s_out', _f), ('s_out', _f), ('s_mid', _p), ('s_res', _p), ('s_next', _p), ('residual', _p),
-                ('inv_s_pe', _f), ('pe_to_embed', _f), ('s_embed', _f), ('pos_deq', _p), ('patches', _i)]
+                ('inv_s_pe', _f), ('pe_to_embed', _f), ('s_embed', _f), ('pos_deq', _p), ('patches', _i), ('gelu', GeluTab)]
 
 
 class Block(C.Structure):
     _fields_ = [('ln1', Ln * 2), ('inv_s_qkv', _f * 2), ('attn', Attn), ('proj_epi', Epilogue), ('ln2', (Ln * 2) * 2),
-                ('inv_s_fc1', _f), ('fc2_epi', Epilogue)]
+                ('inv_s_fc1', _f), ('gelu_fc1', GeluTab), ('fc2_epi', Epilogue)]
 
 
 OP_PATCHIFY, OP_GEMM, OP_LAYERNORM, OP_WINATTN, OP_MERGE, OP_AVGPOOL = range(6)
@@ -111,6 +116,11 @@ def lib():
     L.p2v_fake_quant_f32.argtypes = [_p, _ll, _p, _i, _ll, _i, _i, _p, _p, _p]
     L.p2v_gelu_quant_f32.argtypes = [_p, _ll, _f, _p, _p, _i, _p]
     L.p2v_gelu_err_sweep.argtypes = [C.c_uint32, C.c_uint32, _p, _p]
+    L.p2v_gelu_table_plan.argtypes = [_f, C.POINTER(GeluTab)]
+    L.p2v_gelu_table_scratch_bytes.argtypes = [_i]
+    L.p2v_gelu_table_scratch_bytes.restype = C.c_size_t
+    L.p2v_gelu_table_build.argtypes = [_f, C.POINTER(GeluTab), _p, C.c_size_t, _p]
+    L.p2v_gelu_table_check.argtypes = [_f, C.POINTER(GeluTab), _p, _p]
     if L.p2v_abi_version() != P2V_ABI_VERSION:
         raise RuntimeError('libp2vit_hip.so ABI %d != binding %d: rebuild' % (L.p2v_abi_version(), P2V_ABI_VERSION))
     _lib = L
@@ -131,9 +141,38 @@ def check(rc):
     raise P2VError('p2vit error %d: %s' % (rc, msg))
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """the caller's current HIP stream ON ``device`` (default: the current device)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_GELU_TABLES = {}     # (device index, 1/scale) -> (GeluTab, table tensor): built once per process and device
+
+
+def gelu_table(inv_s, device):
+    """threshold table of GELU -> QAct for the power-of-two multiplier ``inv_s`` on ``device`` (p2v_gelu_table_build: an
+    exhaustive fp32 sweep on the GPU, ~0.1 s, cached), or an empty descriptor when the scale has no table."""
+    import torch
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), float(inv_s))
+    if key not in _GELU_TABLES:
+        L = lib()
+        t = GeluTab()
+        if L.p2v_gelu_table_plan(float(inv_s), C.byref(t)) != 0:
+            _GELU_TABLES[key] = (GeluTab(), None)
+        else:
+            with torch.cuda.device(device):
+                tab = torch.empty(t.cells * 2, dtype=torch.int32, device=device)
+                scratch = torch.empty(L.p2v_gelu_table_scratch_bytes(t.cells), dtype=torch.uint8, device=device)
+                t.table = ptr(tab)
+                rc = L.p2v_gelu_table_build(float(inv_s), C.byref(t), ptr(scratch), scratch.numel(), stream_ptr(device))
+            if rc == E_UNSUPPORTED:
+                _GELU_TABLES[key] = (GeluTab(), None)
+            else:
+                check(rc)
+                _GELU_TABLES[key] = (t, tab)
+    return _GELU_TABLES[key][0]
 
 
 def ptr(t):

@@ -54,6 +54,8 @@ class FrozenPlan:
     def __init__(self, arch, state_dict, calib, device='cuda', in_chans=3):
         self.arch = dict(arch)
         self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.in_chans = in_chans
         self._keep = []          # tensors whose device pointers the C plan borrows
         self._handle = C.c_void_p()
@@ -179,6 +181,7 @@ class FrozenPlan:
             blk.proj_epi = pe
             self._linear_per_bit(3 + 4 * i, W[p + 'mlp.fc1.weight'], cs_m, s_m0, c[p + 'mlp.best_weight_scale'], W[p + 'mlp.fc1.bias'])
             blk.inv_s_fc1 = float(1.0 / s_m1)
+            blk.gelu_fc1 = E.gelu_table(float(1.0 / s_m1), self.device)      # exact GELU -> qact1 threshold table (cached per scale)
             self._linear(4 + 4 * i, W[p + 'mlp.fc2.weight'], None, s_m1, c[p + 'mlp.fc2'], W[p + 'mlp.fc2.bias'])
             fe = E.Epilogue()
             fe.s_mid = E.ptr(self._dev(c[p + 'mlp.qact2'].reshape(-1)))
@@ -224,70 +227,83 @@ class FrozenPlan:
             self._ws_batch = batch
         return self._ws
 
-    def forward(self, images, bit_config, stop_after=-1, out=None):
-        """images: fp32 [B,C,H,W] on the plan's device -> fp32 logits [B, classes] (int8 grid * act_out scale)."""
+    def _check(self, images, bit_config):
+        """the reference's input checks (layers_quant.py:437-439, vit_fquant.py:282) plus what the C ABI trusts: the geometry in
+        the plan descriptor, a device pointer on THIS plan's GPU.  Shared by ``forward``, ``forward_streams`` and ``profile``
+        (a wrong-sized or foreign tensor would otherwise be an out-of-bounds read in ``k_quantize_patchify``)."""
         a = self.arch
         if images.dim() != 4 or images.shape[2] != a['img_size'] or images.shape[3] != a['img_size']:
             raise AssertionError("Input image size (%d*%d) doesn't match model (%d*%d)." % (
-                images.shape[2], images.shape[3], a['img_size'], a['img_size']))      # layers_quant.py:437-439
+                images.shape[2] if images.dim() > 2 else -1, images.shape[3] if images.dim() > 3 else -1, a['img_size'], a['img_size']))
         if images.shape[1] != self.in_chans:
             raise AssertionError('expected %d input channels' % self.in_chans)
         if not images.is_cuda:
             raise RuntimeError('the quantized forward runs on the HIP engine only: move the input to the GPU')
+        if images.device != self.device:
+            raise RuntimeError('images live on %s, the frozen plan on %s' % (images.device, self.device))
+        if images.shape[0] < 1:
+            raise AssertionError('empty batch')
         if bit_config is None:
             raise ValueError('None is not in list')        # bit_pool.index(None), vit_fquant.py:282
-        images = images.contiguous().float()
-        B = images.shape[0]
         cfg = (C.c_int8 * len(bit_config))(*[int(b) if -128 <= int(b) <= 127 else 127 for b in bit_config])
-        ws = self.workspace(B)
-        if out is None:
-            out = torch.empty(B, a['num_classes'], dtype=torch.float32, device=self.device)
-        E.check(E.lib().p2v_forward(self._handle, E.ptr(images), B, cfg, len(bit_config), E.ptr(out), E.ptr(ws),
-                                    ws.numel(), stop_after, E.stream_ptr()))
+        return images.contiguous().float(), cfg
+
+    def forward(self, images, bit_config, stop_after=-1, out=None):
+        """images: fp32 [B,C,H,W] on the plan's device -> fp32 logits [B, classes] (int8 grid * act_out scale)."""
+        images, cfg = self._check(images, bit_config)
+        B = images.shape[0]
+        with torch.cuda.device(self.device):
+            ws = self.workspace(B)
+            if out is None:
+                out = torch.empty(B, self.arch['num_classes'], dtype=torch.float32, device=self.device)
+            E.check(E.lib().p2v_forward(self._handle, E.ptr(images), B, cfg, len(bit_config), E.ptr(out), E.ptr(ws),
+                                        ws.numel(), stop_after, E.stream_ptr(self.device)))
         return out
 
     def forward_streams(self, images, bit_config, out, n_streams=2):
         """Same result as ``forward``; the batch is cut into ``n_streams`` contiguous slices that run on their own HIP
         streams with their own workspaces.  Images are independent, so this is only a scheduling choice: kernels of one
         slice (e.g. a VALU-bound GELU epilogue) overlap latency- or MFMA-bound phases of another slice's kernels."""
-        images = images.contiguous().float()
+        images, cfg = self._check(images, bit_config)
         B = images.shape[0]
         if n_streams <= 1 or B < 2 * n_streams:
             return self.forward(images, bit_config, out=out)
-        cfg = (C.c_int8 * len(bit_config))(*[int(b) for b in bit_config])
-        if getattr(self, '_streams', None) is None or len(self._streams) != n_streams:
-            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
-            self._ws_multi = [None] * n_streams
-        cur = torch.cuda.current_stream(self.device)
-        step = (B + n_streams - 1) // n_streams
-        L = E.lib()
-        for i, st in enumerate(self._streams):
-            lo, hi = i * step, min(B, (i + 1) * step)
-            if lo >= hi:
-                break
-            n = L.p2v_workspace_bytes(self._handle, hi - lo)
-            if self._ws_multi[i] is None or self._ws_multi[i].numel() < n:
-                self._ws_multi[i] = torch.empty(n, dtype=torch.uint8, device=self.device)
-            st.wait_stream(cur)
-            xi, oi = images[lo:hi], out[lo:hi]
-            E.check(L.p2v_forward(self._handle, E.ptr(xi), hi - lo, cfg, len(bit_config), E.ptr(oi), E.ptr(self._ws_multi[i]),
-                                  self._ws_multi[i].numel(), -1, C.c_void_p(st.cuda_stream)))
-        for st in self._streams:
-            cur.wait_stream(st)
+        if tuple(out.shape) != (B, self.arch['num_classes']) or out.device != self.device or out.dtype != torch.float32 or not out.is_contiguous():
+            raise AssertionError('out must be a contiguous fp32 [%d, %d] tensor on %s' % (B, self.arch['num_classes'], self.device))
+        with torch.cuda.device(self.device):
+            if getattr(self, '_streams', None) is None or len(self._streams) != n_streams:
+                self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+                self._ws_multi = [None] * n_streams
+            cur = torch.cuda.current_stream(self.device)
+            step = (B + n_streams - 1) // n_streams
+            L = E.lib()
+            for i, st in enumerate(self._streams):
+                lo, hi = i * step, min(B, (i + 1) * step)
+                if lo >= hi:
+                    break
+                n = L.p2v_workspace_bytes(self._handle, hi - lo)
+                if self._ws_multi[i] is None or self._ws_multi[i].numel() < n:
+                    self._ws_multi[i] = torch.empty(n, dtype=torch.uint8, device=self.device)
+                st.wait_stream(cur)
+                xi, oi = images[lo:hi], out[lo:hi]
+                E.check(L.p2v_forward(self._handle, E.ptr(xi), hi - lo, cfg, len(bit_config), E.ptr(oi), E.ptr(self._ws_multi[i]),
+                                      self._ws_multi[i].numel(), -1, C.c_void_p(st.cuda_stream)))
+            for st in self._streams:
+                cur.wait_stream(st)
         return out
 
     def profile(self, images, bit_config):
         """per-launch times (ms, HIP events on the launch stream) of one forward: [(kind_name, ms), ...]."""
-        images = images.contiguous().float()
+        images, cfg = self._check(images, bit_config)
         B = images.shape[0]
-        cfg = (C.c_int8 * len(bit_config))(*[int(b) for b in bit_config])
-        ws = self.workspace(B)
-        out = torch.empty(B, self.arch['num_classes'], dtype=torch.float32, device=self.device)
-        n_max = 7 * self.depth + 8
-        ms = (C.c_float * n_max)()
-        kind = (C.c_int32 * n_max)()
-        n = E.lib().p2v_forward_profile(self._handle, E.ptr(images), B, cfg, len(bit_config), E.ptr(out), E.ptr(ws), ws.numel(),
-                                        E.stream_ptr(), ms, kind, n_max)
+        with torch.cuda.device(self.device):
+            ws = self.workspace(B)
+            out = torch.empty(B, self.arch['num_classes'], dtype=torch.float32, device=self.device)
+            n_max = 7 * self.depth + 8
+            ms = (C.c_float * n_max)()
+            kind = (C.c_int32 * n_max)()
+            n = E.lib().p2v_forward_profile(self._handle, E.ptr(images), B, cfg, len(bit_config), E.ptr(out), E.ptr(ws), ws.numel(),
+                                            E.stream_ptr(self.device), ms, kind, n_max)
         if n < 0:
             E.check(n)
         return [(E.KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(n)]

@@ -180,8 +180,9 @@ class PtfObserver(BaseObserver):
 
 
 class _FloatScaleObserver(BaseObserver):
-    """FQ-ViT leftovers with float (non power-of-two) scales (observer/{ema,omse,percentile}.py).  Kept so that
-    ``Config(quant_method=...)`` constructs; the integer engine refuses non-PoT activation scales at freeze time."""
+    """FQ-ViT's observers with float (non power-of-two) scales (observer/{ema,omse,percentile}.py): the shared min/max ->
+    (scale, zero_point) step.  They calibrate the module surface like the reference; the integer engine refuses non-PoT
+    activation scales at freeze time (the kernels multiply by exact 1/s)."""
 
     def __init__(self, module_type, bit_type, calibration_mode):
         super().__init__(module_type, bit_type, calibration_mode)
@@ -217,11 +218,49 @@ class EmaObserver(_FloatScaleObserver):
 
 
 class OmseObserver(_FloatScaleObserver):
-    pass
+    """min/max range shrunk by the candidate (of 90, 1 % steps) that minimises the L2 quantisation error of the tensor
+    (omse.py:31-56, after LAPQ).  The result is always the asymmetric (scale, zero_point) pair, as in the reference.
+    Delta: the reference's signature takes ``inputs`` only, so its own QAct/QLinear calls (which pass others/attn keywords,
+    layers.py:68,160,216) raise TypeError; the keywords are accepted and ignored here."""
+
+    def get_quantization_params(self, inputs, *args, **kwargs):
+        qmax, qmin = self.bit_type.upper_bound, self.bit_type.lower_bound
+        hi0, lo0 = self.max_val, self.min_val
+        best, scale, zero_point = 1e+10, None, None
+        for step in range(90):
+            shrink = 1.0 - step * 0.01
+            hi, lo = hi0 * shrink, lo0 * shrink
+            s = ((hi - lo) / float(qmax - qmin)).clamp(self.eps)
+            zp = (qmin - torch.round(lo / s)).clamp(qmin, qmax)
+            err = lp_loss(inputs, ((inputs / s + zp).round().clamp(qmin, qmax) - zp) * s, p=2.0, reduction='all')
+            if err < best:
+                best, scale, zero_point = err, s, zp
+                self.max_val, self.min_val = hi, lo
+        return scale, zero_point
 
 
 class PercentileObserver(_FloatScaleObserver):
-    pass
+    """0.99999 / 0.00001 quantiles of the whole tensor, exponentially averaged over calibration batches (sigma 0.01);
+    layer-wise only (percentile.py:23-52)."""
+
+    def __init__(self, module_type, bit_type, calibration_mode, percentile_sigma=0.01, percentile_alpha=0.99999):
+        super().__init__(module_type, bit_type, calibration_mode)
+        self.percentile_sigma = 0.01          # the reference ignores both constructor arguments (percentile.py:19-20)
+        self.percentile_alpha = 0.99999
+
+    def update(self, v):
+        assert self.calibration_mode == 'layer_wise'
+        flat = self.reshape_tensor(v).reshape(-1)
+        try:
+            cur_max = torch.quantile(flat, self.percentile_alpha)
+            cur_min = torch.quantile(flat, 1.0 - self.percentile_alpha)
+        except RuntimeError:                  # torch.quantile refuses inputs above 16 M elements
+            import numpy as np
+            host = flat.cpu().numpy()
+            cur_max = torch.tensor(np.percentile(host, self.percentile_alpha * 100), device=v.device, dtype=torch.float32)
+            cur_min = torch.tensor(np.percentile(host, (1 - self.percentile_alpha) * 100), device=v.device, dtype=torch.float32)
+        self.max_val = cur_max if self.max_val is None else self.max_val + self.percentile_sigma * (cur_max - self.max_val)
+        self.min_val = cur_min if self.min_val is None else self.min_val + self.percentile_sigma * (cur_min - self.min_val)
 
 
 str2observer = {'minmax': MinmaxObserver, 'ema': EmaObserver, 'omse': OmseObserver, 'percentile': PercentileObserver,

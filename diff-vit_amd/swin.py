@@ -327,7 +327,7 @@ class SwinTransformer(nn.Module):
         return torch.flatten(x, 1)
 
     def forward(self, x, bits=8):
-        if self.quant and not self._calibrating():
+        if self.quant and all(m.quant and not m.calibrate for m in self._q_modules()):   # a per-module .quant = False sends the reference down its float branch
             # ---- THE HOT PATH: HIP kernels through the C ABI ------------------------------------------------------------------
             if self._plan is None or self._plan.bits != bits:
                 self.freeze(x.device if x.is_cuda else None, bits=bits)

@@ -291,6 +291,10 @@ class SwinPlan:
         return dict(ops=arr, n=len(ops), taps=taps, keep=keep)
 
     def _replay(self, images, slot, taps=None, profile=False):
+        with torch.cuda.device(self.device):       # the recorded pointers and the launch stream belong to the plan's GPU
+            return self._replay_on_device(images, slot, taps, profile)
+
+    def _replay_on_device(self, images, slot, taps, profile):
         B = images.shape[0]
         key = (B, slot)
         if key not in self._recorded:
@@ -302,17 +306,17 @@ class SwinPlan:
         L = E.lib()
         if profile:
             ms = (C.c_float * r['n'])()
-            E.check(L.p2v_run_ops_profile(r['ops'], r['n'], E.stream_ptr(), ms))
+            E.check(L.p2v_run_ops_profile(r['ops'], r['n'], E.stream_ptr(self.device), ms))
             return out, list(ms)
         if taps is None:
-            E.check(L.p2v_run_ops(r['ops'], r['n'], E.stream_ptr()))
+            E.check(L.p2v_run_ops(r['ops'], r['n'], E.stream_ptr(self.device)))
             return out
         done = 0
         for upto, name, t_ in r['taps']:          # replay in segments and copy the tapped buffers (they are reused later)
-            E.check(L.p2v_run_ops(C.cast(C.byref(r['ops'], done * C.sizeof(E.Op)), C.POINTER(E.Op)), upto - done, E.stream_ptr()))
+            E.check(L.p2v_run_ops(C.cast(C.byref(r['ops'], done * C.sizeof(E.Op)), C.POINTER(E.Op)), upto - done, E.stream_ptr(self.device)))
             taps[name] = t_[:, :t_.shape[1]].clone()
             done = upto
-        E.check(L.p2v_run_ops(C.cast(C.byref(r['ops'], done * C.sizeof(E.Op)), C.POINTER(E.Op)), r['n'] - done, E.stream_ptr()))
+        E.check(L.p2v_run_ops(C.cast(C.byref(r['ops'], done * C.sizeof(E.Op)), C.POINTER(E.Op)), r['n'] - done, E.stream_ptr(self.device)))
         return out
 
     def _check_images(self, images):

@@ -313,6 +313,7 @@ class VisionTransformer(nn.Module):
         nn.init.trunc_normal_(self.cls_token, std=0.02)
         self.apply(self._init_weights)
         self._plan = None
+        self._qmods = None
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
@@ -332,7 +333,9 @@ class VisionTransformer(nn.Module):
 
     # ---- state switches (vit_fquant.py:667-698) ----------------------------------------------------------------
     def _q_modules(self):
-        return [m for m in self.modules() if type(m) in (QConv2d, QLinear, QAct, QIntSoftmax)]
+        if self._qmods is None:               # the module tree is fixed after construction
+            self._qmods = [m for m in self.modules() if type(m) in (QConv2d, QLinear, QAct, QIntSoftmax)]
+        return self._qmods
 
     def model_quant(self, flag='on'):
         if flag == 'on':
@@ -427,9 +430,6 @@ class VisionTransformer(nn.Module):
         return out
 
     # ---- forward -----------------------------------------------------------------------------------------------
-    def _calibrating(self):
-        return any(m.calibrate for m in self._q_modules())
-
     def forward_features(self, x, FLOPs, global_distance, bit_config, global_plot, hessian_statistic=False):
         B = x.shape[0]
         if self.input_quant:
@@ -449,8 +449,14 @@ class VisionTransformer(nn.Module):
         x = self.qact2(x)
         return self.pre_logits(x)
 
+    def _fused(self):
+        """the fused engine replaces the module-by-module graph only in the state ``model_quant()`` leaves behind: the model
+        flag AND every Q-module's own ``.quant`` set (the reference's forward reads the per-module flags, so
+        ``model_dequant()`` or a single ``m.quant = False`` sends it down the float branch of that module)."""
+        return self.quant and all(m.quant and not m.calibrate for m in self._q_modules())
+
     def forward(self, x, bit_config=None, plot=False, hessian_statistic=False):
-        if self.quant and not self._calibrating() and not hessian_statistic:
+        if self._fused() and not hessian_statistic:
             # ---- THE HOT PATH: fused HIP engine -----------------------------------------------------------------
             if bit_config is None:
                 raise ValueError('None is not in list')          # bit_pool.index(None), vit_fquant.py:282

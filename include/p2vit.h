@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define P2V_ABI_VERSION 1
+#define P2V_ABI_VERSION 2
 
 enum {
   P2V_OK = 0,
@@ -98,6 +98,15 @@ typedef struct p2v_attn {
   int32_t x0_int, b_int, c_int; /* I-BERT exp polynomial constants (layers.py:334-351) for sf = qact_attn1 scale */
 } p2v_attn;
 
+/* nn.GELU -> QAct(PoT) (layers_quant.py:331-333) as an exact threshold table built by p2v_gelu_table_build:
+ *   cell i = clamp(floor(fma(y, k, off)), 0, cells-1) of the fp32 pre-activation y;  entry = { float thr; uint32 lo | hi << 8 };
+ *   code = (y >= thr) ? (int8)hi : (int8)lo.   table == NULL selects the arithmetic evaluation (A&S erfc + fp64 fallback). */
+typedef struct p2v_gelu_tab {
+  const void* table; /* dev [cells] 8-byte entries, or NULL */
+  float k, off;      /* k = 2 / s_out (a power of two: y*k is exact), off = -floor(y_lo * k)            */
+  int32_t cells;
+} p2v_gelu_tab;
+
 /* Epilogue parameters; which members are read depends on the epilogue kind. */
 typedef struct p2v_epilogue {
   float inv_s_out;       /* REQUANT/GELU/HEAD: 1/scale of the following QAct (pot)           */
@@ -112,6 +121,7 @@ typedef struct p2v_epilogue {
   float s_embed;         /* qact_embed scale                                                  */
   const float* pos_deq;  /* dev [tokens][N]  qact_pos(pos_embed), dequantised                 */
   int32_t patches;       /* patches per image; output row = b*(patches+1) + 1 + p             */
+  p2v_gelu_tab gelu;     /* GELU only: threshold table for inv_s_out (optional)              */
 } p2v_epilogue;
 
 typedef struct p2v_plan p2v_plan;
@@ -138,6 +148,7 @@ typedef struct p2v_block {
   p2v_epilogue proj_epi;    /* RESID */
   p2v_ln ln2[2][2];         /* [bit index of qkv (attn.channel_scale quirk, vit_fquant.py:464)][bit index of fc1] */
   float inv_s_fc1;          /* 1/mlp.qact1 scale */
+  p2v_gelu_tab gelu_fc1;    /* threshold table of fc1 -> GELU -> qact1 for inv_s_fc1 (table may be NULL) */
   p2v_epilogue fc2_epi;     /* RESID */
 } p2v_block;
 int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk);
@@ -265,6 +276,19 @@ int p2v_run_ops_profile(const p2v_op* ops, int n_ops, void* stream, float* ms);
  * dimension: element i uses scale[(i / inner) % n_scale].  codes (optional) receives the int8 codes. */
 int p2v_fake_quant_f32(const float* x, long long n, const float* scale, int n_scale, long long inner,
                        int lo, int hi, float* out, int8_t* codes, void* stream);
+
+/* Exact GELU -> requant threshold table for inv_s = 2^e, 0 <= e <= 12 (mlp.qact1 scale, layers_quant.py:331-333).
+ *   p2v_gelu_table_plan   fills t->k, t->off, t->cells (t->table untouched); P2V_E_UNSUPPORTED when inv_s is not such a power
+ *                         of two or the table would exceed 4096 cells (callers then leave table == NULL).
+ *   p2v_gelu_table_build  t->table = dev buffer of t->cells * 8 bytes, scratch = dev buffer of p2v_gelu_table_scratch_bytes;
+ *                         sweeps EVERY finite fp32 with the fp64 erfc on `stream` and SYNCHRONISES it (one-off, plan building):
+ *                         P2V_E_UNSUPPORTED if some cell would need two thresholds.
+ *   p2v_gelu_table_check  counts (into *mismatches, dev, zeroed by the caller) the finite fp32 values whose table code
+ *                         differs from clamp(rne(RN32(gelu(y)) * inv_s)); asynchronous.                                    */
+int p2v_gelu_table_plan(float inv_s, p2v_gelu_tab* t);
+size_t p2v_gelu_table_scratch_bytes(int cells);
+int p2v_gelu_table_build(float inv_s, const p2v_gelu_tab* t, void* scratch, size_t scratch_bytes, void* stream);
+int p2v_gelu_table_check(float inv_s, const p2v_gelu_tab* t, unsigned long long* mismatches, void* stream);
 
 /* correctly-rounded fp32 GELU followed by PoT quantisation (checks the fast path of the GELU epilogue
  * against its own fp64 slow path; flags[0] counts slow-path lanes). */

@@ -202,3 +202,65 @@ def test_qintlayernorm_module_vs_randomised_reference_vectors():
         with torch.no_grad():
             y = ln(torch.from_numpy(g[p + 'codes']).float() * full.reshape(1, 1, -1), qi, qo, None, ex)
         assert np.array_equal(y.numpy(), g[p + 'out'], equal_nan=True), i
+
+
+def test_float_scale_observers_match_reference():
+    """EmaObserver / OmseObserver / PercentileObserver (FQ-ViT's non power-of-two observers, selectable through
+    ``--quant-method``) against outputs of the REAL reference classes (tests/golden/kat_observers.npz, oracle/gen_golden_observers.py)."""
+    from conftest import load_golden
+    import diff_vit_amd as dva
+    from diff_vit_amd.ptq.observer import build_observer
+    g = load_golden('kat_observers')
+    xs = [torch.from_numpy(g['x/%d' % i]) for i in range(3)]
+    w = torch.from_numpy(g['w'])
+    for name in ('ema', 'omse', 'percentile'):
+        for bt in ('int8', 'uint8'):
+            for mode in ('layer_wise', 'channel_wise'):
+                if name == 'percentile' and mode == 'channel_wise':
+                    with pytest.raises(AssertionError):
+                        build_observer(name, 'activation', dva.BIT_TYPE_DICT[bt], mode).update(xs[0])
+                    continue
+                ob = build_observer(name, 'activation', dva.BIT_TYPE_DICT[bt], mode)
+                for x in xs:
+                    ob.update(x)
+                # the product's QAct passes the fork's extra keywords (layers.py:216); they must be accepted
+                s, zp = ob.get_quantization_params(xs[-1], attn=False, attn_para=None)
+                key = '%s/act/%s/%s' % (name, bt, mode)
+                assert np.array_equal(np.asarray(s.numpy()), g[key + '/scale']), key
+                assert np.array_equal(np.asarray(zp.numpy()), g[key + '/zp']), key
+                assert np.array_equal(np.asarray(ob.max_val.numpy()), g[key + '/max']), key
+                assert np.array_equal(np.asarray(ob.min_val.numpy()), g[key + '/min']), key
+        ob = build_observer(name, 'linear_weight', dva.BIT_TYPE_DICT['int8'], 'layer_wise')
+        ob.update(w)
+        s, zp = ob.get_quantization_params(w, others=[None])
+        assert np.array_equal(np.asarray(s.numpy()), g['%s/w/scale' % name]) and np.array_equal(np.asarray(zp.numpy()), g['%s/w/zp' % name]), name
+
+
+def test_model_dequant_leaves_the_fused_path_like_the_reference(dva, micro):
+    """model_quant(); model_dequant() (vit_fquant.py:680-683) clears the per-module flags the reference's forward reads: the
+    module-by-module graph runs again (NOT the float model: QIntLayerNorm stays in mode 'int', the softmax stays log-int).
+    A single module with ``.quant = False`` does the same.  Expected logits: the REAL reference in the same states
+    (tests/golden/micro_vit_dequant.npz, oracle/gen_golden_dequant.py).  All on CPU: the engine is never touched."""
+    from conftest import load_golden
+    gd = load_golden('micro_vit_dequant')
+    m = _micro_model(dva, micro)
+    x = micro['x_ev']
+    with torch.no_grad():
+        dva.harness.calibrate_model(m, micro['x_cal'])
+        assert m._fused()
+        with pytest.raises(RuntimeError):
+            m(x, [8] * 10)                        # quant state on a CPU tensor: the engine refuses, no fallback
+        m.model_dequant()
+        assert not m._fused()
+        for tag, bits in (('q8', 8), ('q4', 4)):
+            out = m(x, [bits] * 10)[0]
+            assert np.abs(out.numpy() - gd['dequant/' + tag]).max() <= 1e-5, tag
+        m.model_quant()
+        assert m._fused()
+        m.blocks[0].mlp.fc2.quant = False
+        assert not m._fused()
+        out = m(x, [8] * 10)[0]                   # module-by-module graph (torch fake-quant) with fc2 of block 0 in float
+    # fake-quant graph on the int8 grid: the canonical sums vs torch-CPU sums may move single codes (DESIGN section 2)
+    s_o = float(m.act_out.quantizer.scale)
+    assert np.abs(out.numpy() - gd['fc2_float/q8']).max() <= 1.01 * s_o
+    assert float((out.numpy() == gd['fc2_float/q8']).mean()) > 0.9
