@@ -45,6 +45,8 @@ def algorithmic_work(kind, arch, B):
         'gemm_fc1': g(M, D, Hd),
         'gemm_fc2': g(M, Hd, D, extra=M * D),
         'gemm_head': g(B, D, arch['num_classes'], out_b=4),
+        'ln_gemm_qkv': g(M, D, 3 * D),           # LayerNorm fused in: reads the residual codes, writes the qkv codes
+        'ln_gemm_fc1': g(M, D, Hd),
     }[kind]
 
 

@@ -59,6 +59,8 @@ extern "C" {
 extern int g_ln_generic;
 extern int g_ln_rows;
 extern int g_attn_waves;
+extern int g_gemm_stages;
+extern int g_ln_gemm;
 // Tuning / A-B switches read once per process (first plan or first version query).  None of them changes results:
 // P2V_LN_GENERIC forces the generic LayerNorm chain (bit-identical to the fast one, both are tested).
 static void read_env_once() {
@@ -67,6 +69,10 @@ static void read_env_once() {
   done = true;
   const char* e = getenv("P2V_ATTN_WAVES");
   if (e && atoi(e) >= 4 && atoi(e) <= 8) g_attn_waves = atoi(e);
+  e = getenv("P2V_GEMM_STAGES");
+  if (e && (atoi(e) == 0 || atoi(e) == 2 || atoi(e) == 3)) g_gemm_stages = atoi(e);
+  e = getenv("P2V_LN_GEMM");
+  if (e) g_ln_gemm = atoi(e) != 0;
   e = getenv("P2V_LN_ROWS");
   if (e && atoi(e) >= 1 && atoi(e) <= 64) g_ln_rows = atoi(e);
   e = getenv("P2V_LN_GENERIC");
@@ -94,7 +100,7 @@ int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
   p->k_patch_pad = round_up(p->k_patch, GBK_PAD);
   p->n_layers = 4 * d.depth + 2;
   for (int b = 0; b < 2; ++b) {
-    p->lin[b].assign(p->n_layers, p2v_linear{nullptr, nullptr, nullptr});
+    p->lin[b].assign(p->n_layers, p2v_linear{nullptr, nullptr, nullptr, nullptr});
     p->lin_set[b].assign(p->n_layers, 0);
   }
   p->blocks.resize(d.depth);
@@ -194,6 +200,20 @@ static int run_gemm(int epi, const int8_t* A, int lda, int M, int K, int N, cons
   return launch_rc(p2v_launch_gemm(epi, g, st), "gemm_i8");
 }
 
+// QIntLayerNorm -> /cs -> qact0 -> QLinear -> (GELU) -> QAct in one launch (k_ln_gemm); a.out may be null
+static int run_ln_gemm(int epi, const LnArgs& a, const p2v_linear& lin, const p2v_epilogue& ep, int N, int8_t* out, hipStream_t st) {
+  GemmArgs g;
+  if (!lin.w_frag) return fail(P2V_E_UNSUPPORTED, "ln_gemm: the layer has no fragment-order weights (p2v_linear.w_frag)");
+  g.A = nullptr; g.lda = a.C; g.M = (int)a.rows; g.W = lin.w_frag; g.K = round_up(a.C, GBK_PAD); g.N = N;
+  g.colscale = lin.colscale; g.bias = lin.bias; g.ep = ep; g.out = out; g.ldo = N; g.out_codes = nullptr; g.tiles_n = 0;
+#ifdef P2V_DIAG
+  g.stamps = nullptr;
+#endif
+  const int rc = p2v_launch_ln_gemm(epi, a, g, st);
+  if (rc == -3) return fail(P2V_E_UNSUPPORTED, "ln_gemm: shape C=%d N=%d is not fused", a.C, N);
+  return launch_rc(rc, "ln_gemm");
+}
+
 struct Prof {
   std::vector<hipEvent_t> ev;   // ev[i] recorded before launch i; one more after the last
   std::vector<int> kind;        // P2V_K_* of launch i
@@ -221,6 +241,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
   const p2v_model_desc& d = p->d;
   const int D = d.embed_dim, T = p->tokens, M = batch * T, Hd = d.mlp_hidden, hd = D / d.num_heads;
   int launched = 0, rc;
+  const bool taps = stop_after >= 0;      // parity runs read the workspace buffers: the fused kernels then also write the LayerNorm codes
 #define STEP(kind_, call)                             \
   do {                                                \
     if (stop_after >= 0 && launched >= stop_after) return P2V_OK; \
@@ -233,7 +254,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     }                                                 \
     rc = (call);                                      \
     if (rc) return rc;                                \
-    ++launched;                                       \
+    launched += (kind_ == P2V_K_LN_GEMM_QKV || kind_ == P2V_K_LN_GEMM_FC1) ? 2 : 1;   /* a fused launch fills two slots of the stop_after numbering */ \
   } while (0)
 
   // qact_input + PatchEmbed + cls/pos/qact1                                 vit_fquant.py:705-733
@@ -251,11 +272,16 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     const int bq = bit_index(bc[0]), bp = bit_index(bc[1]), b1 = bit_index(bc[2]), b2 = bit_index(bc[3]);
     // norm1 -> /channel_scale -> qact0                                     vit_fquant.py:431-434,284-289
     LnArgs ln{bufX, D, M, D, b.ln1[bq], bufLN, D};
-    STEP(P2V_K_LAYERNORM, launch_rc(p2v_launch_layernorm(ln, st), "int_layernorm"));
     // qkv -> qact1                                                          vit_fquant.py:293,307
     p2v_epilogue e{};
     e.inv_s_out = b.inv_s_qkv[bq];
-    STEP(P2V_K_GEMM_QKV, run_gemm(P2V_EPI_REQUANT, bufLN, D, M, D, 3 * D, p->lin[bq][1 + 4 * i], e, bufQKV, 3 * D, nullptr, st));
+    if (p->lin[bq][1 + 4 * i].w_frag && p2v_ln_gemm_supported(P2V_EPI_REQUANT, D, 3 * D, 0)) {              // one launch: the LayerNorm output stays in LDS
+      if (!taps) ln.out = nullptr;
+      STEP(P2V_K_LN_GEMM_QKV, run_ln_gemm(P2V_EPI_REQUANT, ln, p->lin[bq][1 + 4 * i], e, 3 * D, bufQKV, st));
+    } else {
+      STEP(P2V_K_LAYERNORM, launch_rc(p2v_launch_layernorm(ln, st), "int_layernorm"));
+      STEP(P2V_K_GEMM_QKV, run_gemm(P2V_EPI_REQUANT, bufLN, D, M, D, 3 * D, p->lin[bq][1 + 4 * i], e, bufQKV, 3 * D, nullptr, st));
+    }
     // scores -> qact_attn1 -> log-int-softmax -> @v -> qact2                vit_fquant.py:309-326
     AttnArgs at{bufQKV, batch, T, d.num_heads, b.attn, bufATT, nullptr};
     STEP(P2V_K_ATTENTION, launch_rc(p2v_launch_attention(at, hd, st), "lis_attention"));
@@ -265,12 +291,17 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     STEP(P2V_K_GEMM_PROJ, run_gemm(P2V_EPI_RESID, bufATT, D, M, D, D, p->lin[bp][2 + 4 * i], ep, bufX, D, nullptr, st));
     // norm2 (attention's channel scale!) -> /mlp.channel_scale -> mlp.qact0 vit_fquant.py:464, layers_quant.py:305-311
     LnArgs ln2{bufX, D, M, D, b.ln2[bq][b1], bufLN, D};
-    STEP(P2V_K_LAYERNORM, launch_rc(p2v_launch_layernorm(ln2, st), "int_layernorm"));
     // fc1 -> GELU -> qact1                                                  layers_quant.py:316,331-333
     p2v_epilogue e1{};
     e1.inv_s_out = b.inv_s_fc1;
     e1.gelu = b.gelu_fc1;
-    STEP(P2V_K_GEMM_FC1, run_gemm(P2V_EPI_GELU, bufLN, D, M, D, Hd, p->lin[b1][3 + 4 * i], e1, bufHID, Hd, nullptr, st));
+    if (p->lin[b1][3 + 4 * i].w_frag && p2v_ln_gemm_supported(P2V_EPI_GELU, D, Hd, e1.gelu.table ? e1.gelu.cells : 0)) {
+      if (!taps) ln2.out = nullptr;
+      STEP(P2V_K_LN_GEMM_FC1, run_ln_gemm(P2V_EPI_GELU, ln2, p->lin[b1][3 + 4 * i], e1, Hd, bufHID, st));
+    } else {
+      STEP(P2V_K_LAYERNORM, launch_rc(p2v_launch_layernorm(ln2, st), "int_layernorm"));
+      STEP(P2V_K_GEMM_FC1, run_gemm(P2V_EPI_GELU, bufLN, D, M, D, Hd, p->lin[b1][3 + 4 * i], e1, bufHID, Hd, nullptr, st));
+    }
     // fc2 -> qact2 -> + x -> Block.qact4                                    layers_quant.py:342-346, vit_fquant.py:468
     p2v_epilogue e2 = b.fc2_epi;
     e2.residual = bufX;
@@ -350,6 +381,20 @@ int p2v_int_layernorm(const int8_t* x, long long row_stride, int rows, int C, co
   if (rows <= 0) return fail(P2V_E_SHAPE, "rows must be positive");
   LnArgs a{x, row_stride, rows, C, *ln, out, out_stride};
   return launch_rc(p2v_launch_layernorm(a, (hipStream_t)stream), "int_layernorm");
+}
+
+int p2v_ln_gemm_i8(int kind, const int8_t* x, long long row_stride, int M, int C, const p2v_ln* ln, int N, const p2v_linear* lin,
+                   const p2v_epilogue* epi, int8_t* out, int ldo, int8_t* ln_out, void* stream) {
+  if (!x || !ln || !lin || !epi || !out) return fail(P2V_E_ARG, "p2v_ln_gemm_i8: null argument");
+  if (kind != P2V_EPI_REQUANT && kind != P2V_EPI_GELU) return fail(P2V_E_ARG, "p2v_ln_gemm_i8: epilogue %d (REQUANT and GELU are fused)", kind);
+  if (M <= 0 || C <= 0 || N <= 0) return fail(P2V_E_SHAPE, "p2v_ln_gemm_i8: bad shape");
+  if (C % 4 || row_stride % 4 || N % 16 || ldo != N) return fail(P2V_E_UNSUPPORTED, "p2v_ln_gemm_i8: C, row_stride multiples of 4; N multiple of 16; ldo == N");
+  if (kind == P2V_EPI_REQUANT && !(is_pot(epi->inv_s_out) && epi->inv_s_out >= 0x1p-40f && epi->inv_s_out <= 0x1p40f))
+    return fail(P2V_E_UNSUPPORTED, "REQUANT: 1/scale %g must be a power of two (it is folded into the column scales)", epi->inv_s_out);
+  if (kind == P2V_EPI_GELU && epi->gelu.table && (epi->gelu.cells <= 0 || epi->gelu.cells > 4096)) return fail(P2V_E_ARG, "GELU table with %d cells", epi->gelu.cells);
+  read_env_once();
+  LnArgs a{x, row_stride, M, C, *ln, ln_out, C};
+  return run_ln_gemm(kind, a, *lin, *epi, N, out, (hipStream_t)stream);
 }
 
 int p2v_lis_attention(const int8_t* qkv, int batch, int tokens, int heads, int head_dim, const p2v_attn* at, int8_t* out,

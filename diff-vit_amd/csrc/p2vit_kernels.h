@@ -59,6 +59,8 @@ int p2v_launch_patchify(const float* img, int B, int C, int H, int W, int P, flo
 int p2v_launch_fill_cls(int8_t* x, int B, int T, int D, const int8_t* cls, hipStream_t st);
 int p2v_launch_gemm(int epi, const GemmArgs& g, hipStream_t st);
 int p2v_launch_layernorm(const LnArgs& a, hipStream_t st);
+bool p2v_ln_gemm_supported(int epi, int C, int N, int table_cells);
+int p2v_launch_ln_gemm(int epi, const LnArgs& a, const GemmArgs& g, hipStream_t st);   // -3: shape not fused
 int p2v_launch_attention(const AttnArgs& a, int head_dim, hipStream_t st);
 int p2v_launch_fake_quant(const float* x, long long n, const float* scale, int n_scale, long long inner, int lo, int hi,
                           float* out, int8_t* codes, hipStream_t st);

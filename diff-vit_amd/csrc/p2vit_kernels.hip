@@ -149,11 +149,24 @@ __device__ __forceinline__ int gelu_code_exact(float y, float inv_s) {
   asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:BYTE_" #B " dst_unused:" UNUSED              \
       " src0_sel:BYTE_0 src1_sel:BYTE_1"                                                                                   \
       : "+v"(DST) : "v"(YV), "v"(__uint_as_float(ENT.x)), "v"(ENT.y) : "vcc")
-// four outputs of one lane -> one dword of int8 codes
+// four outputs of one lane -> one dword of int8 codes.  ASM_LDS: the table is in LDS and is read with inline-asm ds_read_b64
+// (a kernel with LDS-DMA requests in flight: hipcc would put s_waitcnt vmcnt(0) in front of an LDS read it can see).
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+template <bool ASM_LDS = false>
 __device__ __forceinline__ unsigned gelu_tab_q8x4(const float (&y)[4], const unsigned char* tab, float k, float off, float tmax) {
   uint2 e[4];
+  if (ASM_LDS) {
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)tab;
+    v2u r0, r1, r2, r3;
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                 : "v"(base + gelu_tab_offset(y[0], k, off, tmax)), "v"(base + gelu_tab_offset(y[1], k, off, tmax)),
+                   "v"(base + gelu_tab_offset(y[2], k, off, tmax)), "v"(base + gelu_tab_offset(y[3], k, off, tmax)));
+    e[0] = make_uint2(r0[0], r0[1]); e[1] = make_uint2(r1[0], r1[1]); e[2] = make_uint2(r2[0], r2[1]); e[3] = make_uint2(r3[0], r3[1]);
+  } else {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) e[i] = *reinterpret_cast<const uint2*>(tab + gelu_tab_offset(y[i], k, off, tmax));
+    for (int i = 0; i < 4; ++i) e[i] = *reinterpret_cast<const uint2*>(tab + gelu_tab_offset(y[i], k, off, tmax));
+  }
   unsigned d = 0;
   P2V_GELU_SEL(0, "UNUSED_PAD", d, y[0], e[0]);
   P2V_GELU_SEL(1, "UNUSED_PRESERVE", d, y[1], e[1]);
@@ -336,7 +349,7 @@ __device__ __forceinline__ void gemm_stage_epilogue(EpiLds* e, int n0, int tid, 
   }
 }
 
-template <int EPI>
+template <int EPI, bool ASM_LDS = false>
 __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n_tile, int nl, int h, const GemmArgs& g,
                                                    const EpiLds* e, uint4 resv, const unsigned char* gtab = nullptr) {
   // lane owns output row m, channels n_tile + 8*gq + 4*h + {0..3}, gq = 0..3   (C/D map of 32x32 MFMA);
@@ -355,8 +368,14 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
     const int n = n_tile + 8 * gq + 4 * h, c = nl + 8 * gq + 4 * h;
-    const float4 cs = *reinterpret_cast<const float4*>(e->colscale + c);
-    const float4 bs = *reinterpret_cast<const float4*>(e->bias + c);
+    float4 cs, bs;
+    if (ASM_LDS) {   // see gelu_tab_q8x4
+      const unsigned ea = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)(e->colscale + c);
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cs), "=&v"(bs) : "v"(ea));
+    } else {
+      cs = *reinterpret_cast<const float4*>(e->colscale + c);
+      bs = *reinterpret_cast<const float4*>(e->bias + c);
+    }
     float y[4];
     // F.linear / F.conv2d on fake-quantised operands: exact integer sum * (s_x*s_w[n]), then ONE rounding
     // for the fp32 bias (layers.py:87,178).  The product int * 2^k is exact, so the fused multiply-add rounds
@@ -367,7 +386,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
     y[3] = __builtin_fmaf((float)acc[4 * gq + 3], cs.w, bs.w);
     float q[4];                 // integral floats; the byte packing below saturates to [-128,127]
     if (EPI == P2V_EPI_GELU_TAB) {
-      d[gq] = gelu_tab_q8x4(y, gtab, g.ep.gelu.k, g.ep.gelu.off, (float)(g.ep.gelu.cells - 1));
+      d[gq] = gelu_tab_q8x4<ASM_LDS>(y, gtab, g.ep.gelu.k, g.ep.gelu.off, (float)(g.ep.gelu.cells - 1));
       continue;
     }
     if (EPI == P2V_EPI_REQUANT) {
@@ -641,6 +660,162 @@ __global__ __launch_bounds__(256, 3) void k_gemm_i8_w4(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K1d: the tiled GEMM with LDS-DMA staging (global_load_lds_dwordx4, gfx950).
+//   Why: in k_gemm_i8_w4 every k-tile moves 16 KB global -> VGPR -> ds_write_b128 -> LDS.  ds_write_b128 sustains ~79 B/clk per
+//   CU (13 cycles per wave-instruction), i.e. ~207 cycles of the CU's one LDS store path per workgroup and k-tile; with three
+//   workgroups per CU that is ~620 cycles per round of k-tiles beside 768 cycles of MFMA and ~380 cycles of fragment reads on the
+//   same LDS: the k-loop was bound by LDS, not by the matrix pipe (measured 1.1 k cycles per k-tile).  The DMA writes LDS without
+//   passing through registers: no ds_write at all, and the 48 staging VGPRs of the 3-deep register ring are gone (one more wave
+//   per SIMD).
+//   Layout per stage: X tile [128][64] at +0, W tile [128][64] at +8192, both with the 16-byte chunk XOR swizzle of lds_off64.
+//   A DMA wave-instruction fills 1 KB = 16 rows x 64 B linearly (lane l -> row l>>2, slot l&3), so the swizzle goes on the
+//   per-lane SOURCE address: slot s of row r receives logical chunk s ^ ((r>>2)&3).
+//   Synchronisation (NST = 3 stages, one barrier per k-tile): tile t+2 is requested right after the barrier of tile t, into the
+//   stage tile t-1 was read from (every wave has passed barrier t only after finishing tile t-1).  A wave waits for ITS OWN
+//   pieces of tile t with a counted s_waitcnt vmcnt(4) (the 4 younger requests of tile t+1 stay in flight), then joins the
+//   barrier.  NST = 2: a second barrier after the reads of tile t guards the refill of its stage.
+//   The fragment reads are inline-asm ds_read_b128: hipcc puts s_waitcnt vmcnt(0) in front of every LDS access it can see while a
+//   DMA is pending (it cannot prove they do not alias), which would serialise the pipeline; __syncthreads() likewise drains vmcnt,
+//   hence the raw s_barrier.
+// ---------------------------------------------------------------------------------------------------
+#define DMA_STAGE_BYTES (2 * GBM * GBK)     // 16 KB: X tile + W tile
+template <int OFF>
+__device__ __forceinline__ void gemm_compute_tile_dma(unsigned aX0, unsigned aX1, unsigned aW0, unsigned aW1, v16i (&acc)[2][2]) {
+  // a*: LDS byte addresses of this lane's fragment rows at k-step 0; k-step 1 is the same address with bit 5 flipped (chunk ^ 2)
+  v4i x0a, x1a, w0a, w1a, x0b, x1b, w0b, w1b;
+  const unsigned bX0 = aX0 ^ 32u, bX1 = aX1 ^ 32u, bW0 = aW0 ^ 32u, bW1 = aW1 ^ 32u;
+  asm volatile(
+      "ds_read_b128 %0, %8 offset:%16\n\tds_read_b128 %1, %9 offset:%16\n\tds_read_b128 %2, %10 offset:%16\n\tds_read_b128 %3, %11 offset:%16\n\t"
+      "ds_read_b128 %4, %12 offset:%16\n\tds_read_b128 %5, %13 offset:%16\n\tds_read_b128 %6, %14 offset:%16\n\tds_read_b128 %7, %15 offset:%16\n\t"
+      "s_waitcnt lgkmcnt(4)"
+      : "=&v"(w0a), "=&v"(w1a), "=&v"(x0a), "=&v"(x1a), "=&v"(w0b), "=&v"(w1b), "=&v"(x0b), "=&v"(x1b)
+      : "v"(aW0), "v"(aW1), "v"(aX0), "v"(aX1), "v"(bW0), "v"(bW1), "v"(bX0), "v"(bX1), "i"(OFF)
+      : "memory");
+  acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0a, x0a, acc[0][0], 0, 0, 0);
+  acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0a, x1a, acc[0][1], 0, 0, 0);
+  acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1a, x0a, acc[1][0], 0, 0, 0);
+  acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1a, x1a, acc[1][1], 0, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0b), "+v"(w1b), "+v"(x0b), "+v"(x1b));   // the k-step-1 fragments are ordered behind this wait
+  acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0b, x0b, acc[0][0], 0, 0, 0);
+  acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0b, x1b, acc[0][1], 0, 0, 0);
+  acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1b, x0b, acc[1][0], 0, 0, 0);
+  acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1b, x1b, acc[1][1], 0, 0, 0);
+}
+
+template <int EPI, int NST>
+__global__ __launch_bounds__(256, NST == 2 ? 4 : 3) void k_gemm_dma(GemmArgs g) {
+  constexpr int EPI_BYTES = (EPI == P2V_EPI_RESID) ? (int)sizeof(EpiLds) : 2 * GBN * (int)sizeof(float);   // colscale + bias only
+  __shared__ __attribute__((aligned(1024))) int8_t lds[NST * DMA_STAGE_BYTES + EPI_BYTES];
+  EpiLds* sE = reinterpret_cast<EpiLds*>(lds + NST * DMA_STAGE_BYTES);
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];   // GELU threshold table (cells * 8 bytes)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bid = blockIdx.x, nt = gridDim.x, xcd = bid & 7, qd = nt >> 3, rm = nt & 7;
+  int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  const int tn = t % g.tiles_n, tm = t / g.tiles_n;
+  const int m0 = tm * GBM, n0 = tn * GBN;
+
+  // ---- DMA source addresses: wave w moves rows [32w, 32w+32) of both tiles, two 16-row pieces each
+  const int lr = lane >> 2, pc = lane & 3;
+  const int ra = 32 * wave + lr, rb = ra + 16;
+  int mra = m0 + ra, mrb = m0 + rb;
+  mra = mra < g.M ? mra : g.M - 1;
+  mrb = mrb < g.M ? mrb : g.M - 1;
+  const int8_t* gxa = g.A + (long long)mra * g.lda + ((pc ^ ((ra >> 2) & 3)) << 4);
+  const int8_t* gxb = g.A + (long long)mrb * g.lda + ((pc ^ ((rb >> 2) & 3)) << 4);
+  const int8_t* gwa = g.W + (long long)(n0 + ra) * g.K + ((pc ^ ((ra >> 2) & 3)) << 4);
+  const int8_t* gwb = g.W + (long long)(n0 + rb) * g.K + ((pc ^ ((rb >> 2) & 3)) << 4);
+  auto dma = [&](int stage, int kt) {
+    int8_t* dst = lds + stage * DMA_STAGE_BYTES + wave * (32 * GBK);
+    const int ko = kt * GBK;
+#define P2V_DMA16_(SRC, DST) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
+    P2V_DMA16_(gxa + ko, dst);
+    P2V_DMA16_(gxb + ko, dst + 16 * GBK);
+    P2V_DMA16_(gwa + ko, dst + GBM * GBK);
+    P2V_DMA16_(gwb + ko, dst + GBM * GBK + 16 * GBK);
+#undef P2V_DMA16_
+  };
+  const int nk = g.K / GBK;
+  dma(0, 0);
+  if (nk > 1) dma(1, 1);
+
+  // ---- epilogue constants / GELU table (compiler-visible LDS stores: they may wait for the requests above, which the first
+  //      k-tile needs anyway); residual codes requested early
+  gemm_stage_epilogue<EPI>(sE, n0, tid, g);
+  if (EPI == P2V_EPI_GELU_TAB)
+    for (int i = tid; i < g.ep.gelu.cells; i += 256)
+      reinterpret_cast<uint2*>(dyn_lds)[i] = reinterpret_cast<const uint2*>(g.ep.gelu.table)[i];
+  uint4 resv[2][2];
+  if (EPI == P2V_EPI_RESID) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 64 + ni * 32 + 16 * h;
+        resv[ni][mi] = make_uint4(0, 0, 0, 0);
+        if (m < g.M && n < g.N) resv[ni][mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
+      }
+  }
+
+  v16i acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+
+  const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int8_t*)lds;
+  const unsigned aX0 = lbase + lds_off64(wm * 64 + l31, h), aX1 = lbase + lds_off64(wm * 64 + 32 + l31, h);
+  const unsigned aW0 = lbase + GBM * GBK + lds_off64(wn * 64 + l31, h), aW1 = lbase + GBM * GBK + lds_off64(wn * 64 + 32 + l31, h);
+
+  // one k-tile: own pieces landed (younger requests stay in flight) -> barrier -> refill the freed stage -> MFMAs
+#define P2V_KTILE(S, KT)                                                                                             \
+  do {                                                                                                               \
+    if (NST == 3) {                                                                                                  \
+      /* in flight behind tile KT: tile KT+1 (4 requests of this wave) */                                            \
+      if ((KT) + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                            \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+      asm volatile("s_barrier" ::: "memory");    /* tile KT landed for everyone; everyone is done reading tile KT-1 */ \
+      if ((KT) + 2 < nk) dma(((S) + 2) % 3, (KT) + 2);                                                               \
+      gemm_compute_tile_dma<(S) * DMA_STAGE_BYTES>(aX0, aX1, aW0, aW1, acc);                                         \
+    } else {                                                                                                         \
+      if ((KT) + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                            \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+      asm volatile("s_barrier" ::: "memory");                                                                        \
+      gemm_compute_tile_dma<(S) * DMA_STAGE_BYTES>(aX0, aX1, aW0, aW1, acc);                                         \
+      if ((KT) + 2 < nk) {                                                                                           \
+        asm volatile("s_barrier" ::: "memory");                                                                      \
+        dma((S), (KT) + 2);                                                                                          \
+      }                                                                                                              \
+    }                                                                                                                \
+  } while (0)
+  if (NST == 3) {
+    for (int kt = 0; kt < nk; kt += 3) {
+      P2V_KTILE(0, kt);
+      if (kt + 1 < nk) P2V_KTILE(1, kt + 1);
+      if (kt + 2 < nk) P2V_KTILE(2, kt + 2);
+    }
+  } else {
+    for (int kt = 0; kt < nk; kt += 2) {
+      P2V_KTILE(0, kt);
+      if (kt + 1 < nk) P2V_KTILE(1, kt + 1);
+    }
+  }
+#undef P2V_KTILE
+  __syncthreads();        // nothing is in flight any more; orders the constant stores before the epilogue reads for every wave
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+      gemm_epilogue_tile<EPI>(acc[ni][mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, sE,
+                              EPI == P2V_EPI_RESID ? resv[ni][mi] : make_uint4(0, 0, 0, 0), dyn_lds);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K2: integer LayerNorm (QIntLayerNorm mode 'int', layers.py:255-289) + /channel_scale + qact0 clamp
 // (vit_fquant.py:284-289).  One row per 32-lane half wave (12 bytes/lane at C=384), LN_ROWS rows per half
 // wave so the five per-channel constant vectors stay in registers.  sum x and sum x^2 are exact integers;
@@ -679,23 +854,32 @@ __device__ __forceinline__ float ln_elem_generic(float xq, float g, float bta, f
 // rint(((sM*xq + Bv) rounded) * 2^-N) == rint(fma(T, xq, Bv*2^-N))  because T*xq is exact (8 x 11 bits) and scaling by
 // 2^-N commutes with the rounding.  Bit-identical to the generic chain (tests drive both through P2V_LN_GENERIC=1).
 // LANES = 32: one row per half wave (C <= 1024);  LANES = 64: one row per wave (PatchMerging rows of up to 2048 channels)
+// per-lane view of the folded per-channel constants of a LayerNorm (held in registers across rows)
+template <int NCH>
+struct LnLane {
+  bool on[NCH];
+  float4 gm[NCH], bt[NCH], pm[NCH];   // gamma*io, beta*io, post_mul
+  int4 mki[NCH];                      // PTF mask (in_scale / s1)
+  float gmin, gmax;                   // extreme |gamma*io| over all channels
+  bool pot;                           // 1/out_scale is a power of two for every channel and the fold is exact
+};
+
+// Fold, test and publish the per-channel constants once per workgroup (every thread calls it; contains a barrier), then load this
+// lane's channels: lane l of a row group owns channels (l + LANES*i)*4 .. +3.
 template <int NCH, int LANES>
-__global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
-  // per-channel constants are folded once per workgroup, shared through LDS, then held in registers (re-reading them from
-  // LDS per row frees 46 VGPRs but measured 10 % slower: the kernel is bound by VALU issue, not by occupancy)
-  __shared__ __attribute__((aligned(16))) float sG[NCH * LANES * 4], sB[NCH * LANES * 4], sP[NCH * LANES * 4];
-  __shared__ __attribute__((aligned(16))) int sM[NCH * LANES * 4];
-  const int tid = threadIdx.x, l32 = tid & (LANES - 1), hw = tid / LANES;   // l32: lane within the row group
-  int potf = a.force_generic ? 0 : 1;
-  for (int t4 = tid; t4 < NCH * LANES; t4 += 256) {   // one thread per 4 channels: fold, test, and publish
+__device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_generic, float* sG, float* sB, float* sP, int* sM,
+                                           int tid, int nthreads, LnLane<NCH>& L) {
+  const int l32 = tid & (LANES - 1);
+  int potf = force_generic ? 0 : 1;
+  for (int t4 = tid; t4 < NCH * LANES; t4 += nthreads) {   // one thread per 4 channels: fold, test, and publish
     const int c = t4 * 4;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f), b = g, io = make_float4(1.f, 1.f, 1.f, 1.f), pmv = g, mk = g;
-    if (c < a.C) {
-      g = *reinterpret_cast<const float4*>(a.ln.gamma + c);
-      b = *reinterpret_cast<const float4*>(a.ln.beta + c);
-      io = *reinterpret_cast<const float4*>(a.ln.inv_out + c);
-      pmv = *reinterpret_cast<const float4*>(a.ln.post_mul + c);
-      mk = *reinterpret_cast<const float4*>(a.ln.mask + c);
+    if (c < C) {
+      g = *reinterpret_cast<const float4*>(ln.gamma + c);
+      b = *reinterpret_cast<const float4*>(ln.beta + c);
+      io = *reinterpret_cast<const float4*>(ln.inv_out + c);
+      pmv = *reinterpret_cast<const float4*>(ln.post_mul + c);
+      mk = *reinterpret_cast<const float4*>(ln.mask + c);
     }
     const float g4[4] = {g.x, g.y, g.z, g.w}, b4[4] = {b.x, b.y, b.z, b.w}, i4[4] = {io.x, io.y, io.z, io.w};
     float go[4], bo[4];
@@ -716,25 +900,22 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
     *reinterpret_cast<float4*>(sP + c) = pmv;
     *reinterpret_cast<int4*>(sM + c) = make_int4((int)mk.x, (int)mk.y, (int)mk.z, (int)mk.w);
   }
-  const bool pot = __syncthreads_and(potf) != 0;
-  bool on[NCH];
-  float4 gm[NCH], bt[NCH], pm[NCH];
-  int4 mki[NCH];
-  // extreme |g io| over all channels (every half wave covers all of them)
+  L.pot = __syncthreads_and(potf) != 0;
+  // extreme |g io| over all channels (every row group covers all of them)
   float gmin = 3.0e38f, gmax = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = (l32 + LANES * i) * 4;
-    on[i] = c < a.C;
+    L.on[i] = c < C;
     const float4 gv = *reinterpret_cast<const float4*>(sG + c);
-    gm[i] = gv;
-    bt[i] = *reinterpret_cast<const float4*>(sB + c);
-    pm[i] = *reinterpret_cast<const float4*>(sP + c);
-    mki[i] = *reinterpret_cast<const int4*>(sM + c);
+    L.gm[i] = gv;
+    L.bt[i] = *reinterpret_cast<const float4*>(sB + c);
+    L.pm[i] = *reinterpret_cast<const float4*>(sP + c);
+    L.mki[i] = *reinterpret_cast<const int4*>(sM + c);
     const float lo = fminf(fminf(fabsf(gv.x), fabsf(gv.y)), fminf(fabsf(gv.z), fabsf(gv.w)));
     const float hi = fmaxf(fmaxf(fabsf(gv.x), fabsf(gv.y)), fmaxf(fabsf(gv.z), fabsf(gv.w)));
-    gmin = fminf(gmin, on[i] ? lo : 3.0e38f);
-    gmax = fmaxf(gmax, on[i] ? hi : 0.f);
+    gmin = fminf(gmin, L.on[i] ? lo : 3.0e38f);
+    gmax = fmaxf(gmax, L.on[i] ? hi : 0.f);
   }
   {   // positive floats order like their bit patterns: integer min/max butterflies inside the half wave
     int lo = (int)__float_as_uint(gmin), hi = (int)__float_as_uint(gmax);
@@ -747,12 +928,97 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
       lo = min(lo, __shfl_xor(lo, 32));
       hi = max(hi, __shfl_xor(hi, 32));
     }
-    gmin = __uint_as_float((unsigned)lo);
-    gmax = __uint_as_float((unsigned)hi);
+    L.gmin = __uint_as_float((unsigned)lo);
+    L.gmax = __uint_as_float((unsigned)hi);
   }
-  const float s1 = a.ln.s1;
-  const float Cf = (float)a.C;
+}
+
+// One row: packed input codes wcur[i] (0 where the lane's channels lie past C) -> packed output codes outw[i].  Every lane of the
+// row group (32 or 64 lanes) must call it: the sums are cross-lane reductions.
+template <int NCH, int LANES>
+__device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane<NCH>& L, const p2v_ln& ln, int C, int l32, unsigned (&outw)[NCH]) {
+  const float s1 = ln.s1;
+  const float Cf = (float)C;
   const float s1oC = s1 / Cf;
+  float xq[NCH][4];
+  int S1 = 0;
+  unsigned S2 = 0;                              // C * (128*8)^2 <= 2^31 for C <= 2048: exact in 32 unsigned bits
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const unsigned w = wcur[i];
+    const int m4[4] = {L.mki[i].x, L.mki[i].y, L.mki[i].z, L.mki[i].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int v = __mul24(sx8(w, j), m4[j]);           // x_q * in_scale_mask  (layers.py:269-273); w == 0 past C
+      xq[i][j] = (float)v;
+      S1 += v;
+      S2 += (unsigned)__mul24(v, v);
+    }
+  }
+  S1 = half_wave_sum(S1);
+  S2 = (unsigned)half_wave_sum((int)S2);        // two's-complement adds: the unsigned total is exact
+  if (LANES == 64) {
+    S1 += __shfl_xor(S1, 32);
+    S2 += (unsigned)__shfl_xor((int)S2, 32);
+  }
+  const float S1f = (float)S1, S2f = (float)S2;
+  const float mean = (S1f / Cf) * s1;                                  // x_q.mean(-1) * in_scale1
+  const float stdv = s1oC * sqrtf(Cf * S2f - S1f * S1f);               // layers.py:276-277
+  const float rs = s1 / stdv;
+  const float mos = mean / stdv;
+  // |A| = RN(rs*|g io|) is monotone in |g io|: the two extreme channels bound every channel exactly
+  const bool fast = L.pot && rs * L.gmin >= 0x1p-24f && rs * L.gmax < 256.f;
+  if (fast) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const float g4[4] = {L.gm[i].x, L.gm[i].y, L.gm[i].z, L.gm[i].w}, b4[4] = {L.bt[i].x, L.bt[i].y, L.bt[i].z, L.bt[i].w};
+      const float p4[4] = {L.pm[i].x, L.pm[i].y, L.pm[i].z, L.pm[i].w};
+      float q[4];
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {   // two channels at a time: the multiplies, the subtraction and the fma are v_pk_*_f32
+        const v2f g2 = {g4[j], g4[j + 1]}, b2 = {b4[j], b4[j + 1]}, p2 = {p4[j], p4[j + 1]}, x2 = {xq[i][j], xq[i][j + 1]};
+        const v2f A2 = (v2f){rs, rs} * g2;
+        const v2f t2 = b2 - (v2f){mos, mos} * g2;
+        v2f T2, Bq2;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const unsigned Ab = __float_as_uint(A2[e]);
+          T2[e] = __uint_as_float(Ab & 0xFFFF0000u);                              // sign * M * 2^-N
+          const int N = 134 - (int)((Ab >> 23) & 255u);                           // in [0, 31] by the range test
+          Bq2[e] = ldexpf(rintf(ldexpf(t2[e], N)), -N);                           // Bv * 2^-N
+        }
+        const v2f o2 = __builtin_elementwise_fma(T2, x2, Bq2);
+        const v2f q2 = (v2f){rintf(o2[0]), rintf(o2[1])} * p2;
+        q[j] = rintf(q2[0]);
+        q[j + 1] = rintf(q2[1]);
+      }
+      outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int cc = L.on[i] ? (l32 + LANES * i) * 4 : 0;
+      const float4 gv = *reinterpret_cast<const float4*>(ln.gamma + cc), bv = *reinterpret_cast<const float4*>(ln.beta + cc);
+      const float4 iv = *reinterpret_cast<const float4*>(ln.inv_out + cc), pv = *reinterpret_cast<const float4*>(ln.post_mul + cc);
+      const float g4[4] = {gv.x, gv.y, gv.z, gv.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
+      const float i4[4] = {iv.x, iv.y, iv.z, iv.w}, p4[4] = {pv.x, pv.y, pv.z, pv.w};
+      float q[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = ln_elem_generic(xq[i][j], g4[j], b4[j], i4[j], p4[j], rs, mos);
+      outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
+    }
+  }
+}
+
+template <int NCH, int LANES>
+__global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
+  // per-channel constants are folded once per workgroup, shared through LDS, then held in registers (re-reading them from
+  // LDS per row frees 46 VGPRs but measured 10 % slower: the kernel is bound by VALU issue, not by occupancy)
+  __shared__ __attribute__((aligned(16))) float sG[NCH * LANES * 4], sB[NCH * LANES * 4], sP[NCH * LANES * 4];
+  __shared__ __attribute__((aligned(16))) int sM[NCH * LANES * 4];
+  const int tid = threadIdx.x, l32 = tid & (LANES - 1), hw = tid / LANES;   // l32: lane within the row group
+  LnLane<NCH> L;
+  ln_prepare<NCH, LANES>(a.ln, a.C, a.force_generic != 0, sG, sB, sP, sM, tid, 256, L);
   const int LN_ROWS = a.rows_per_half;
   const long long row0 = ((long long)blockIdx.x * (256 / LANES) + hw) * LN_ROWS;
   // Row r+1 is requested at the top of the iteration of row r and first touched just before the stores of row r.  The two
@@ -760,7 +1026,7 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
   // behind the stores, and waits vmcnt(0) there - two exposed memory round trips per row (measured: 3 us per row).
   int colofs[NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) colofs[i] = on[i] ? (l32 + LANES * i) * 4 : 0;     // clamped: loads are unconditional
+  for (int i = 0; i < NCH; ++i) colofs[i] = L.on[i] ? (l32 + LANES * i) * 4 : 0;     // clamped: loads are unconditional
   const long long last_row = a.rows - 1;
   unsigned wnext[NCH];
 #pragma unroll
@@ -774,88 +1040,177 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
     if (row >= a.rows) break;   // uniform within the half wave; the reductions below stay inside 32 lanes
     unsigned wcur[NCH];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) wcur[i] = on[i] ? wnext[i] : 0u;
+    for (int i = 0; i < NCH; ++i) wcur[i] = L.on[i] ? wnext[i] : 0u;
     {
       const long long nrow = row + 1 < a.rows ? row + 1 : last_row;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) wnext[i] = *reinterpret_cast<const unsigned*>(a.x + nrow * a.row_stride + colofs[i]);
       asm volatile("" ::: "memory");                 // the loads stay above this line
     }
-    float xq[NCH][4];
-    int S1 = 0;
-    unsigned S2 = 0;                              // C * (128*8)^2 <= 2^31 for C <= 2048: exact in 32 unsigned bits
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const unsigned w = wcur[i];
-      const int m4[4] = {mki[i].x, mki[i].y, mki[i].z, mki[i].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int v = __mul24(sx8(w, j), m4[j]);           // x_q * in_scale_mask  (layers.py:269-273); w == 0 past C
-        xq[i][j] = (float)v;
-        S1 += v;
-        S2 += (unsigned)__mul24(v, v);
-      }
-    }
-    S1 = half_wave_sum(S1);
-    S2 = (unsigned)half_wave_sum((int)S2);        // two's-complement adds: the unsigned total is exact
-    if (LANES == 64) {
-      S1 += __shfl_xor(S1, 32);
-      S2 += (unsigned)__shfl_xor((int)S2, 32);
-    }
-    const float S1f = (float)S1, S2f = (float)S2;
-    const float mean = (S1f / Cf) * s1;                                  // x_q.mean(-1) * in_scale1
-    const float stdv = s1oC * sqrtf(Cf * S2f - S1f * S1f);               // layers.py:276-277
-    const float rs = s1 / stdv;
-    const float mos = mean / stdv;
     unsigned outw[NCH];
-    // |A| = RN(rs*|g io|) is monotone in |g io|: the two extreme channels bound every channel exactly
-    const bool fast = pot && rs * gmin >= 0x1p-24f && rs * gmax < 256.f;
-    if (fast) {
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const float g4[4] = {gm[i].x, gm[i].y, gm[i].z, gm[i].w}, b4[4] = {bt[i].x, bt[i].y, bt[i].z, bt[i].w};
-        const float p4[4] = {pm[i].x, pm[i].y, pm[i].z, pm[i].w};
-        float q[4];
-#pragma unroll
-        for (int j = 0; j < 4; j += 2) {   // two channels at a time: the multiplies, the subtraction and the fma are v_pk_*_f32
-          const v2f g2 = {g4[j], g4[j + 1]}, b2 = {b4[j], b4[j + 1]}, p2 = {p4[j], p4[j + 1]}, x2 = {xq[i][j], xq[i][j + 1]};
-          const v2f A2 = (v2f){rs, rs} * g2;
-          const v2f t2 = b2 - (v2f){mos, mos} * g2;
-          v2f T2, Bq2;
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const unsigned Ab = __float_as_uint(A2[e]);
-            T2[e] = __uint_as_float(Ab & 0xFFFF0000u);                              // sign * M * 2^-N
-            const int N = 134 - (int)((Ab >> 23) & 255u);                           // in [0, 31] by the range test
-            Bq2[e] = ldexpf(rintf(ldexpf(t2[e], N)), -N);                           // Bv * 2^-N
-          }
-          const v2f o2 = __builtin_elementwise_fma(T2, x2, Bq2);
-          const v2f q2 = (v2f){rintf(o2[0]), rintf(o2[1])} * p2;
-          q[j] = rintf(q2[0]);
-          q[j + 1] = rintf(q2[1]);
-        }
-        outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const int cc = on[i] ? (l32 + LANES * i) * 4 : 0;
-        const float4 gv = *reinterpret_cast<const float4*>(a.ln.gamma + cc), bv = *reinterpret_cast<const float4*>(a.ln.beta + cc);
-        const float4 iv = *reinterpret_cast<const float4*>(a.ln.inv_out + cc), pv = *reinterpret_cast<const float4*>(a.ln.post_mul + cc);
-        const float g4[4] = {gv.x, gv.y, gv.z, gv.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
-        const float i4[4] = {iv.x, iv.y, iv.z, iv.w}, p4[4] = {pv.x, pv.y, pv.z, pv.w};
-        float q[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) q[j] = ln_elem_generic(xq[i][j], g4[j], b4[j], i4[j], p4[j], rs, mos);
-        outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
-      }
-    }
+    ln_row<NCH, LANES>(wcur, L, a.ln, a.C, l32, outw);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(wnext[i]));   // the wait for row r+1 lands here, ahead of the stores
     int8_t* dst = a.out + row * a.out_stride;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
-      if (on[i]) *reinterpret_cast<unsigned*>(dst + (l32 + LANES * i) * 4) = outw[i];
+      if (L.on[i]) *reinterpret_cast<unsigned*>(dst + (l32 + LANES * i) * 4) = outw[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2b: LayerNorm fused into the GEMM that consumes it (norm1 -> qkv, norm2 -> fc1):  QIntLayerNorm 'int' -> /channel_scale ->
+//   qact0 -> QLinear -> (GELU ->) QAct   (vit_fquant.py:431-434,284-293,307; layers_quant.py:305-316,331-333).
+//   X-stationary: a workgroup owns 64 rows.  Prologue = the LayerNorm kernel's row code (ln_prepare / ln_row); its output codes
+//   go to an LDS panel [K/64][64 rows][64 B] instead of HBM.  Main loop over the 128-column tiles of the layer: wave w computes
+//   all 64 rows x columns [32w, 32w+32), so the W rows it needs are its own.  The plan stores these weights a second time in
+//   MFMA-FRAGMENT ORDER (p2v_linear.w_frag: [column tile][wave][k-step][lane][16 B]), so the A operand of every MFMA is one fully
+//   coalesced 1 KB global load straight into registers: no LDS staging for W, no barrier in the main loop, and all waits are
+//   the compiler's own exact scoreboard (an LDS-DMA ring version of this kernel spent ~700 of 890 cycles per k-step on manual
+//   wait counting, M0 set-up and DMA issue; profiles/r02_ln_gemm_timeline.txt).  The W fragments of column tile j+1 are requested
+//   into the registers tile j has just consumed, one k-step behind the MFMAs: a full tile of lead.
+//   What it removes per block: two LayerNorm launches, 2 x (read + write of the residual-sized tensor), and every re-read of the
+//   activation panel by the 9 / 12 column-tile workgroups of the tiled kernel.
+// ---------------------------------------------------------------------------------------------------
+#define LG_BM 64
+struct LnGemmLds {                        // byte offsets inside the dynamic LDS allocation
+  int panel, consts, fold, table, total;
+};
+__host__ __device__ inline LnGemmLds ln_gemm_lds(int K, int N, int nch, int table_cells) {
+  LnGemmLds o;
+  const int kt = (K + GBK - 1) / GBK, tiles_n = (N + GBN - 1) / GBN;
+  o.panel = 0;
+  o.consts = o.panel + kt * LG_BM * GBK;
+  o.fold = o.consts + tiles_n * GBN * 2 * (int)sizeof(float);
+  o.table = o.fold + 4 * nch * 128 * (int)sizeof(float);
+  o.total = o.table + table_cells * 8;
+  return o;
+}
+
+#ifdef P2V_DIAG
+#define LG_STAMP(slot)                                                                                              \
+  do {                                                                                                              \
+    if (g.stamps && threadIdx.x == 0 && (slot) < 62) g.stamps[(long long)blockIdx.x * 64 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define LG_STAMP(slot) do { } while (0)
+#endif
+template <int EPI, int KT>               // KT = k-tiles of 64 channels (C <= 64*KT)
+__global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
+  constexpr int NCH = (KT + 1) / 2;      // 128-channel groups of a LayerNorm row
+  constexpr int NI = 2 * KT;             // k-steps of 32
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lg_smem[];
+  LG_STAMP(0);
+  const int C = a.C;
+  const int cells = EPI == P2V_EPI_GELU_TAB ? g.ep.gelu.cells : 0;
+  const LnGemmLds lay = ln_gemm_lds(C, g.N, NCH, cells);
+  int8_t* panel = reinterpret_cast<int8_t*>(lg_smem + lay.panel);
+  float* consts = reinterpret_cast<float*>(lg_smem + lay.consts);      // per column tile: colscale[128] | bias[128]
+  const unsigned char* gtab = lg_smem + lay.table;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int m0 = blockIdx.x * LG_BM;
+  const int tiles_n = g.tiles_n;
+
+  // ---- W fragments of column tile 0 (registers): element ((j*4 + wave)*NI + i)*64 + lane of 16 bytes
+  const uint4* wsrc = reinterpret_cast<const uint4*>(g.W) + (long long)wave * NI * 64 + lane;
+  v4i wf[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) wf[i] = __builtin_bit_cast(v4i, wsrc[i * 64]);
+
+  // ---- per-column constants of the whole layer (REQUANT: 2^e folded in, see gemm_stage_epilogue) and the GELU table
+  {
+    const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : 1.0f;
+    for (int n = tid; n < tiles_n * GBN; n += 256) {
+      const int j_ = n >> 7, c_ = n & (GBN - 1);
+      consts[j_ * 2 * GBN + c_] = g.colscale[n] * fold;               // arrays are padded to n_pad
+      consts[j_ * 2 * GBN + GBN + c_] = g.bias[n] * fold;
+    }
+    if (EPI == P2V_EPI_GELU_TAB)
+      for (int i = tid; i < cells; i += 256)
+        reinterpret_cast<uint2*>(lg_smem + lay.table)[i] = reinterpret_cast<const uint2*>(g.ep.gelu.table)[i];
+  }
+  LG_STAMP(1);
+  // ---- LayerNorm of the 64 rows -> LDS panel (and, on request, HBM): one row per half wave, 8 rows each, all loads up front
+  {
+    float* sG = reinterpret_cast<float*>(lg_smem + lay.fold);
+    float* sB = sG + NCH * 128;
+    float* sP = sB + NCH * 128;
+    int* sM = reinterpret_cast<int*>(sP + NCH * 128);
+    LnLane<NCH> L;
+    ln_prepare<NCH, 32>(a.ln, C, a.force_generic != 0, sG, sB, sP, sM, tid, 256, L);
+    const int hw = tid >> 5;
+    int colofs[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) colofs[i] = L.on[i] ? (l31 + 32 * i) * 4 : 0;
+    constexpr int RPH = LG_BM / 8;                                       // rows per half wave
+    unsigned win[RPH][NCH];
+#pragma unroll
+    for (int r = 0; r < RPH; ++r) {
+      long long row = (long long)m0 + hw * RPH + r;
+      row = row < a.rows ? row : a.rows - 1;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) win[r][i] = *reinterpret_cast<const unsigned*>(a.x + row * a.row_stride + colofs[i]);
+    }
+#pragma unroll 1
+    for (int r = 0; r < RPH; ++r) {
+      const int lrow = hw * RPH + r;
+      unsigned wcur[NCH], outw[NCH];
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        unsigned v = win[0][i];
+#pragma unroll
+        for (int rr = 1; rr < RPH; ++rr) v = r == rr ? win[rr][i] : v;   // register select: the row loop stays rolled (code size)
+        wcur[i] = L.on[i] ? v : 0u;
+      }
+      ln_row<NCH, 32>(wcur, L, a.ln, C, l31, outw);
+      const long long row = (long long)m0 + lrow;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (l31 + 32 * i) * 4;
+        if (c < KT * GBK)      // channels past C inside the last k-tile are zero
+          *reinterpret_cast<unsigned*>(panel + (c >> 6) * (LG_BM * GBK) + lrow * GBK + ((((c & 63) >> 4) ^ ((lrow >> 2) & 3)) << 4) + (c & 15)) =
+              L.on[i] ? outw[i] : 0u;
+        if (a.out && L.on[i] && row < a.rows) *reinterpret_cast<unsigned*>(a.out + row * a.out_stride + c) = outw[i];
+      }
+    }
+  }
+  LG_STAMP(2);
+  __syncthreads();        // panel, constants and table are complete
+  LG_STAMP(3);
+
+  // X fragment addresses: rows l31 / 32+l31 of panel k-tile kt, chunk 2*ks + h
+  const int8_t* pXa = panel + lds_off64(l31, h);
+  const int8_t* pXb = panel + lds_off64(32 + l31, h);
+  const int xks = (lds_off64(l31, 2 + h) - lds_off64(l31, h));           // +-32: the k-step-1 chunk of the same row
+  v16i acc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0;
+
+  for (int j = 0; j < tiles_n; ++j) {
+    const bool more = j + 1 < tiles_n;                                   // wave-uniform
+    const uint4* wnext = wsrc + (long long)(j + 1) * 4 * NI * 64;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int off = (i >> 1) * (LG_BM * GBK) + (i & 1) * xks;
+      const v4i xa = *reinterpret_cast<const v4i*>(pXa + off);
+      const v4i xb = *reinterpret_cast<const v4i*>(pXb + off);
+      acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xa, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xb, acc[1], 0, 0, 0);
+      if (more) wf[i] = __builtin_bit_cast(v4i, wnext[i * 64]);          // the fragment of the next column tile, a tile ahead of its use
+    }
+    LG_STAMP(4 + 2 * j);
+    const EpiLds* e = reinterpret_cast<const EpiLds*>(consts + j * 2 * GBN);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      gemm_epilogue_tile<EPI>(acc[mi], m0 + mi * 32 + l31, j * GBN + 32 * wave, 32 * wave, h, g, e, make_uint4(0, 0, 0, 0), gtab);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] = 0;
+    }
+    LG_STAMP(5 + 2 * j);
   }
 }
 
@@ -1307,6 +1662,7 @@ __global__ __launch_bounds__(256) void k_gelu_err_sweep(unsigned first_bits, uns
 // host launchers (called from the C ABI in p2vit_capi.cpp)
 // ---------------------------------------------------------------------------------------------------
 int g_attn_waves = 8;     // P2V_ATTN_WAVES
+int g_gemm_stages = 3;    // P2V_GEMM_STAGES: 2 / 3 = LDS-DMA ring depth of k_gemm_dma, 0 = register-staged k_gemm_i8_w4
 #ifdef P2V_DIAG
 unsigned long long* g_gemm_stamps = nullptr;
 #endif
@@ -1340,17 +1696,24 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   const int tiles_m = (g.M + GBM - 1) / GBM;
   if (epi != P2V_EPI_HEAD && epi != P2V_EPI_EMBED) {
     dim3 grid4(g.tiles_n * tiles_m), block4(256);
-    switch (epi) {
-      case P2V_EPI_REQUANT: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_REQUANT>, grid4, block4, 0, st, g); break;
-      case P2V_EPI_GELU:
-        if (g.ep.gelu.table)
-          hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_GELU_TAB>, grid4, block4, (unsigned)g.ep.gelu.cells * 8u, st, g);
-        else
-          hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_GELU>, grid4, block4, 0, st, g);
-        break;
-      case P2V_EPI_RESID: hipLaunchKernelGGL(k_gemm_i8_w4<P2V_EPI_RESID>, grid4, block4, 0, st, g); break;
-      default: return -1;
+    const unsigned tab_bytes = (epi == P2V_EPI_GELU && g.ep.gelu.table) ? (unsigned)g.ep.gelu.cells * 8u : 0u;
+#define P2V_LAUNCH_TILED(KERNEL)                                                                                          \
+    switch (epi) {                                                                                                        \
+      case P2V_EPI_REQUANT: hipLaunchKernelGGL(KERNEL(P2V_EPI_REQUANT), grid4, block4, 0, st, g); break;                  \
+      case P2V_EPI_GELU:                                                                                                  \
+        if (tab_bytes) hipLaunchKernelGGL(KERNEL(P2V_EPI_GELU_TAB), grid4, block4, tab_bytes, st, g);                     \
+        else hipLaunchKernelGGL(KERNEL(P2V_EPI_GELU), grid4, block4, 0, st, g);                                           \
+        break;                                                                                                            \
+      case P2V_EPI_RESID: hipLaunchKernelGGL(KERNEL(P2V_EPI_RESID), grid4, block4, 0, st, g); break;                      \
+      default: return -1;                                                                                                 \
     }
+#define P2V_K_W4(E) (k_gemm_i8_w4<E>)
+#define P2V_K_DMA2(E) (k_gemm_dma<E, 2>)
+#define P2V_K_DMA3(E) (k_gemm_dma<E, 3>)
+    if (g_gemm_stages == 2) { P2V_LAUNCH_TILED(P2V_K_DMA2) }
+    else if (g_gemm_stages == 3) { P2V_LAUNCH_TILED(P2V_K_DMA3) }
+    else { P2V_LAUNCH_TILED(P2V_K_W4) }
+#undef P2V_LAUNCH_TILED
     CHECK_LAUNCH();
     return 0;
   }
@@ -1362,7 +1725,54 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   return 0;
 }
 
+#ifdef P2V_DIAG
+extern unsigned long long* g_gemm_stamps;
+#endif
 int g_ln_generic = 0;     // P2V_LN_GENERIC=1
+// LayerNorm + GEMM in one launch.  Returns -3 when the shape is outside what the fused kernel is instantiated for (callers then
+// run p2v_launch_layernorm + p2v_launch_gemm).
+int g_ln_gemm = 1;        // P2V_LN_GEMM=0: never fuse (A/B runs)
+bool p2v_ln_gemm_supported(int epi, int C, int N, int table_cells) {
+  if (!g_ln_gemm || (epi != P2V_EPI_REQUANT && epi != P2V_EPI_GELU)) return false;
+  if (C % 4 || C > 384 || N % 16) return false;
+  return ln_gemm_lds(C, N, ((C + GBK - 1) / GBK + 1) / 2, table_cells).total <= 80 * 1024;     // two workgroups per CU
+}
+template <int EPI, int KT>
+static int launch_ln_gemm_t(const LnArgs& a, const GemmArgs& g, int cells, hipStream_t st) {
+  const int smem = ln_gemm_lds(a.C, g.N, (KT + 1) / 2, cells).total;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_gemm<EPI, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((k_ln_gemm<EPI, KT>), dim3((unsigned)((g.M + LG_BM - 1) / LG_BM)), dim3(256), (unsigned)smem, st, a, g);
+  CHECK_LAUNCH();
+  return 0;
+}
+// g0.W must point to the FRAGMENT-ORDER copy of the weights (p2v_linear.w_frag)
+int p2v_launch_ln_gemm(int epi, const LnArgs& a_, const GemmArgs& g0, hipStream_t st) {
+  const int cells = (epi == P2V_EPI_GELU && g0.ep.gelu.table) ? g0.ep.gelu.cells : 0;
+  if (!p2v_ln_gemm_supported(epi, a_.C, g0.N, cells)) return -3;
+  LnArgs a = a_;
+  a.force_generic = g_ln_generic;
+  GemmArgs g = g0;
+  g.tiles_n = (g.N + GBN - 1) / GBN;
+#ifdef P2V_DIAG
+  g.stamps = g_gemm_stamps;
+#endif
+  const int kt = (a.C + GBK - 1) / GBK;
+#define P2V_LG(EPI_)                                                              \
+  switch (kt) {                                                                   \
+    case 1: return launch_ln_gemm_t<EPI_, 1>(a, g, cells, st);                    \
+    case 2: return launch_ln_gemm_t<EPI_, 2>(a, g, cells, st);                    \
+    case 3: return launch_ln_gemm_t<EPI_, 3>(a, g, cells, st);                    \
+    case 4: return launch_ln_gemm_t<EPI_, 4>(a, g, cells, st);                    \
+    case 5: return launch_ln_gemm_t<EPI_, 5>(a, g, cells, st);                    \
+    default: return launch_ln_gemm_t<EPI_, 6>(a, g, cells, st);                   \
+  }
+  if (epi == P2V_EPI_REQUANT) { P2V_LG(P2V_EPI_REQUANT) }
+  if (cells) { P2V_LG(P2V_EPI_GELU_TAB) }
+  P2V_LG(P2V_EPI_GELU)
+#undef P2V_LG
+}
+
 int g_ln_rows = 4;        // P2V_LN_ROWS: consecutive rows per half wave
 int p2v_launch_layernorm(const LnArgs& a_, hipStream_t st) {
   LnArgs a = a_;

@@ -15,7 +15,7 @@ EPI_REQUANT, EPI_GELU, EPI_RESID, EPI_EMBED, EPI_HEAD = 0, 1, 2, 3, 4
 E_ARG, E_BITS, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH, E_STATE = -1, -2, -3, -4, -5, -6, -7
 
 KERNEL_KINDS = ('patchify', 'gemm_embed', 'fill_cls', 'layernorm', 'gemm_qkv', 'attention', 'gemm_proj', 'gemm_fc1',
-                'gemm_fc2', 'gemm_head')
+                'gemm_fc2', 'gemm_head', 'ln_gemm_qkv', 'ln_gemm_fc1')
 
 _f, _i, _p, _ll = C.c_float, C.c_int32, C.c_void_p, C.c_longlong
 
@@ -26,7 +26,7 @@ class ModelDesc(C.Structure):
 
 
 class Linear(C.Structure):
-    _fields_ = [('w_codes', _p), ('colscale', _p), ('bias', _p)]
+    _fields_ = [('w_codes', _p), ('colscale', _p), ('bias', _p), ('w_frag', _p)]
 
 
 class Ln(C.Structure):
@@ -108,6 +108,7 @@ def lib():
     L.p2v_gemm_i8.argtypes = [_i, _p, _i, _i, _i, _i, C.POINTER(Linear), C.POINTER(Epilogue), _p, _i, _p, _p]
     L.p2v_int_layernorm.argtypes = [_p, _ll, _i, _i, C.POINTER(Ln), _p, _ll, _p]
     L.p2v_lis_attention.argtypes = [_p, _i, _i, _i, _i, C.POINTER(Attn), _p, _p, _p]
+    L.p2v_ln_gemm_i8.argtypes = [_i, _p, _ll, _i, _i, C.POINTER(Ln), _i, C.POINTER(Linear), C.POINTER(Epilogue), _p, _i, _p, _p]
     L.p2v_run_ops.argtypes = [C.POINTER(Op), _i, _p]
     L.p2v_run_ops_profile.argtypes = [C.POINTER(Op), _i, _p, C.POINTER(C.c_float)]
     L.p2v_patch_merge_gather.argtypes = [_p, _i, _i, _i, _i, _p, _p]
@@ -173,6 +174,14 @@ def gelu_table(inv_s, device):
                 check(rc)
                 _GELU_TABLES[key] = (t, tab)
     return _GELU_TABLES[key][0]
+
+
+def fragment_order(wp):
+    """int8 weight codes [n_pad (x128)][k_pad (x64)] -> the MFMA-fragment order of ``p2v_linear.w_frag``:
+    [column tile][wave][k-step of 32][lane = 32*h + r][16 bytes] with W[128*tile + 32*wave + r][32*kstep + 16*h + b]."""
+    n_pad, k_pad = wp.shape
+    assert n_pad % 128 == 0 and k_pad % 64 == 0
+    return wp.reshape(n_pad // 128, 4, 32, k_pad // 32, 2, 16).permute(0, 1, 3, 4, 2, 5).contiguous()
 
 
 def ptr(t):

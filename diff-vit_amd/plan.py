@@ -216,7 +216,9 @@ class FrozenPlan:
             cs_col[:N] = (s_x * s_w).expand(N)
             bp = torch.zeros(n_pad)
             bp[:N] = bias
-            lin = E.Linear(E.ptr(self._dev(wp, torch.int8)), E.ptr(self._dev(cs_col)), E.ptr(self._dev(bp)))
+            # qkv / fc1 follow a LayerNorm: a second copy in MFMA-fragment order feeds the fused LayerNorm+GEMM kernel
+            lin = E.Linear(E.ptr(self._dev(wp, torch.int8)), E.ptr(self._dev(cs_col)), E.ptr(self._dev(bp)),
+                           E.ptr(self._dev(E.fragment_order(wp), torch.int8)))
             E.check(L.p2v_plan_set_linear(self._handle, layer, bits, C.byref(lin)))
 
     # ---------------------------------------------------------------------------------------------

@@ -69,6 +69,10 @@ typedef struct p2v_linear {
   const int8_t* w_codes; /* dev */
   const float* colscale; /* dev [n_pad] */
   const float* bias;     /* dev [n_pad] */
+  const int8_t* w_frag;  /* dev, optional (NULL): the same codes in MFMA-fragment order for p2v_ln_gemm_i8 --
+                          * [n_pad/128 column tiles][4 waves][k_pad/32 k-steps][64 lanes][16 bytes], lane = 32*h + r holding
+                          * W[128*tile + 32*wave + r][32*kstep + 16*h .. +16): the A operand of v_mfma_i32_32x32x32_i8 as one
+                          * coalesced 1 KB load per wave */
 } p2v_linear;
 
 /* QIntLayerNorm.forward mode 'int' (layers.py:255-289) fused with the division by the SmoothQuant
@@ -166,7 +170,8 @@ int p2v_forward(p2v_plan* plan, const float* images, int batch, const int8_t* bi
 /* Kernel kinds reported by p2v_forward_profile. */
 enum {
   P2V_K_PATCHIFY = 0, P2V_K_GEMM_EMBED = 1, P2V_K_FILL_CLS = 2, P2V_K_LAYERNORM = 3, P2V_K_GEMM_QKV = 4,
-  P2V_K_ATTENTION = 5, P2V_K_GEMM_PROJ = 6, P2V_K_GEMM_FC1 = 7, P2V_K_GEMM_FC2 = 8, P2V_K_GEMM_HEAD = 9
+  P2V_K_ATTENTION = 5, P2V_K_GEMM_PROJ = 6, P2V_K_GEMM_FC1 = 7, P2V_K_GEMM_FC2 = 8, P2V_K_GEMM_HEAD = 9,
+  P2V_K_LN_GEMM_QKV = 10, P2V_K_LN_GEMM_FC1 = 11   /* LayerNorm fused into the GEMM that consumes it (p2v_ln_gemm_i8) */
 };
 
 /* Same as p2v_forward, with a hipEvent recorded on `stream` between consecutive launches; synchronises on the
@@ -199,6 +204,15 @@ int p2v_gemm_i8(int epilogue_kind, const int8_t* A, int lda, int M, int K, int N
  * touch only the cls rows, vit_fquant.py:766-767). */
 int p2v_int_layernorm(const int8_t* x, long long row_stride, int rows, int C, const p2v_ln* ln,
                       int8_t* out, long long out_stride, void* stream);
+
+/* p2v_int_layernorm followed by p2v_gemm_i8 (REQUANT or GELU) in ONE launch: norm1 -> qkv -> qact1 and norm2 -> fc1 -> GELU -> qact1
+ * (vit_fquant.py:431-434,284-293,307; layers_quant.py:305-316,331-333).  The LayerNorm output codes stay in LDS; ln_out (optional,
+ * dev int8 [M][C]) also receives them.  x: dev int8, row r at x + r*row_stride, C channels; lin: weights [n_pad][round_up(C,64)].
+ * Reads lin->w_frag (fragment-order weights), not lin->w_codes.  Bit-identical to the two separate calls.  P2V_E_UNSUPPORTED when
+ * the shape is not instantiated (C > 384, or the layer's constants do not fit two workgroups per CU) or w_frag is NULL: run the
+ * two calls instead. */
+int p2v_ln_gemm_i8(int epilogue_kind, const int8_t* x, long long row_stride, int M, int C, const p2v_ln* ln, int N,
+                   const p2v_linear* lin, const p2v_epilogue* epi, int8_t* out, int ldo, int8_t* ln_out, void* stream);
 
 /* fused attention core on the int8 qkv tensor [batch*tokens][3*heads*head_dim] (layout of
  * qkv.reshape(B,N,3,H,hd), vit_fquant.py:309-315); out int8 [batch*tokens][heads*head_dim].

@@ -238,6 +238,68 @@ def test_int_layernorm(dva, oracle, C_, rows):
     assert ln.abs().max() > 127
 
 
+@pytest.mark.parametrize('C_,N,M,kind,table,pot', [(384, 1152, 333, 'requant', False, True), (384, 1536, 777, 'gelu', True, True),
+                                                   (384, 1536, 130, 'gelu', False, True), (192, 576, 500, 'requant', False, True),
+                                                   (192, 768, 65, 'gelu', True, False), (64, 192, 197, 'requant', False, True),
+                                                   (64, 256, 70, 'gelu', True, True), (96, 288, 100, 'requant', False, True)])
+def test_ln_gemm_fused_vs_separate_and_oracle(dva, oracle, C_, N, M, kind, table, pot):
+    """p2v_ln_gemm_i8 (LayerNorm in the prologue of the qkv / fc1 GEMM, its output kept in LDS) against p2v_int_layernorm followed by
+    p2v_gemm_i8 (bit-identical, incl. the LayerNorm codes written on request) and against the oracle's LayerNorm + qgemm (+ GELU)."""
+    E, S = dva.engine, dva.synth
+    tag = 'f%d_%d' % (C_, N)
+    codes = _rand_codes(S, 13, tag + 'x', (1, M, C_), 35.0)
+    codes[0, 0] = torch.round(codes[0, 0] * 0.03)
+    in_scale = 0.0123 * 2.0 ** torch.floor(S.uniform(13, tag + 'm', (C_,), 0, 3.99))
+    gamma = S.uniform(13, tag + 'g', (C_,), -1.5, 1.5); beta = S.normal(13, tag + 'b', (C_,), 0.3)
+    cs = 2.0 ** torch.floor(S.uniform(13, tag + 'c', (C_,), -2, 2.99))
+    s_a = 2.0 ** -4
+    out_scale = s_a * cs * (1.0 if pot else 1.3)             # 1.3: not a power of two -> the generic LayerNorm chain
+    post = out_scale / cs / s_a if pot else torch.ones(C_)
+    s1 = in_scale.min()
+    k_pad = (C_ + 63) // 64 * 64
+    w = _rand_codes(S, 13, tag + 'w', (N, C_), 30.0)
+    bias = S.normal(13, tag + 'bb', (N,), 0.4)
+    s_w = torch.full((N,), 2.0 ** -7); s_w[::3] = 2.0 ** -6
+    n_pad = (N + 127) // 128 * 128
+    wp = torch.zeros(n_pad, k_pad, dtype=torch.int8); wp[:N, :C_] = w.to(torch.int8)
+    csl = torch.zeros(n_pad); csl[:N] = s_a * s_w
+    bp = torch.zeros(n_pad); bp[:N] = bias
+    d = [t.contiguous().cuda() for t in (codes[0].to(torch.int8), torch.round(in_scale / s1), gamma, beta, 1.0 / out_scale, post, wp, csl, bp)]
+    lnp = E.Ln(float(s1), *[E.ptr(t) for t in d[1:6]])
+    wfrag = E.fragment_order(wp).cuda()
+    lin = E.Linear(E.ptr(d[6]), E.ptr(d[7]), E.ptr(d[8]), E.ptr(wfrag))
+    epi = E.Epilogue()
+    s_out = 2.0 ** -3 if kind == 'requant' else 2.0 ** -5
+    epi.inv_s_out = 1.0 / s_out
+    ek = E.EPI_REQUANT if kind == 'requant' else E.EPI_GELU
+    if table:
+        epi.gelu = E.gelu_table(1.0 / s_out, 'cuda')
+    L = E.lib()
+    # separate calls (the LayerNorm output padded to k_pad columns for the GEMM)
+    ln_sep = torch.zeros(M, k_pad, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_int_layernorm(E.ptr(d[0]), C_, M, C_, C.byref(lnp), E.ptr(ln_sep), k_pad, E.stream_ptr()))
+    out_sep = torch.zeros(M, N, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_gemm_i8(ek, E.ptr(ln_sep), k_pad, M, k_pad, N, C.byref(lin), C.byref(epi), E.ptr(out_sep), N, None, E.stream_ptr()))
+    # fused
+    ln_f = torch.full((M, C_), 99, dtype=torch.int8, device='cuda')
+    out_f = torch.full((M, N), 77, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_ln_gemm_i8(ek, E.ptr(d[0]), C_, M, C_, C.byref(lnp), N, C.byref(lin), C.byref(epi), E.ptr(out_f), N, E.ptr(ln_f), E.stream_ptr()))
+    out_g = torch.full((M, N), 55, dtype=torch.int8, device='cuda')          # without the optional LayerNorm output
+    E.check(L.p2v_ln_gemm_i8(ek, E.ptr(d[0]), C_, M, C_, C.byref(lnp), N, C.byref(lin), C.byref(epi), E.ptr(out_g), N, None, E.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(ln_f, ln_sep[:, :C_])
+    assert torch.equal(out_f, out_sep), int((out_f != out_sep).sum())
+    assert torch.equal(out_g, out_sep)
+    if pot:
+        ln = oracle.int_layernorm(codes * in_scale.reshape(1, 1, -1), in_scale, gamma, beta, out_scale)
+        q0 = torch.clamp(torch.round((ln * out_scale.reshape(1, 1, -1)) / cs.reshape(1, 1, -1) / s_a), -128, 127)[0]
+        assert torch.equal(ln_f.cpu().float(), q0)
+        y = oracle.qgemm(q0, torch.tensor(s_a), w, s_w, bias)
+        v = oracle.gelu_rn(y) if kind == 'gelu' else y
+        ref = torch.clamp(torch.round(v / s_out), -128, 127)
+        assert torch.equal(out_f.cpu().float(), ref), int((out_f.cpu().float() != ref).sum())
+
+
 @pytest.mark.parametrize('B,N,H,hd,e_at', [(2, 17, 2, 32, 4), (3, 49, 4, 32, 5), (2, 197, 3, 64, 4), (1, 197, 6, 64, 6), (2, 50, 2, 64, 3)])
 def test_lis_attention(dva, oracle, B, N, H, hd, e_at):
     E, S = dva.engine, dva.synth
