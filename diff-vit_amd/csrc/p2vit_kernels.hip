@@ -251,19 +251,19 @@ __device__ __forceinline__ float div_q8f(float x, float s, float rs) {
 }
 template <bool CLAMP>
 __device__ __forceinline__ void div_q8fx4(const float (&x)[4], const float (&s)[4], const float (&rs)[4], float (&out)[4]) {
-  float r[4];
-  bool slow[4], any = false;
+  float r[4], dv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float t = x[i] * rs[i];
     r[i] = rintf(t);
-    slow[i] = !rne_decided(t, r[i], 1.0e-4f);
-    any |= slow[i];
+    dv[i] = t - r[i];
   }
-  if (__builtin_amdgcn_ballot_w64(any) != 0) {
+  // ONE test for the four values: max |t - r| (two v_max3 with |.| modifiers) against the margin
+  const float dmax = fmaxf(fmaxf(fmaxf(fabsf(dv[0]), fabsf(dv[1])), fabsf(dv[2])), fabsf(dv[3]));
+  if (__builtin_amdgcn_ballot_w64(!(dmax < 0.5f - 1.0e-4f)) != 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (slow[i]) r[i] = rintf(x[i] / s[i]);
+      if (!(fabsf(dv[i]) < 0.5f - 1.0e-4f)) r[i] = rintf(x[i] / s[i]);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) out[i] = CLAMP ? fminf(fmaxf(r[i], -128.f), 127.f) : r[i];   // unclamped when the caller packs (saturating)
@@ -322,7 +322,7 @@ __device__ __forceinline__ int lds_off64(int row, int chunk) { return row * GBK 
 
 // per-block staging of the per-channel epilogue constants (read by every lane of the block)
 struct EpiLds {
-  float colscale[GBN], bias[GBN], s_mid[GBN], s_res[GBN], s_next[GBN], r_mid[GBN], r_next[GBN];
+  float colscale[GBN], bias[GBN], s_mid[GBN], s_res[GBN], s_next[GBN], r_mid[GBN], r_next[GBN], m128_sres[GBN];   // m128_sres = -128 * s_res (exact)
 };
 
 template <int EPI>
@@ -339,7 +339,9 @@ __device__ __forceinline__ void gemm_stage_epilogue(EpiLds* e, int n0, int tid, 
       const float sm = ok ? g.ep.s_mid[n] : 1.f;
       e->s_mid[tid] = sm;
       e->r_mid[tid] = 1.0f / sm;
-      e->s_res[tid] = ok ? g.ep.s_res[n] : 1.f;
+      const float srs = ok ? g.ep.s_res[n] : 1.f;
+      e->s_res[tid] = srs;
+      e->m128_sres[tid] = -128.f * srs;
     }
     if (EPI == P2V_EPI_RESID || EPI == P2V_EPI_EMBED) {
       const float sn = ok ? g.ep.s_next[n] : 1.f;
@@ -403,10 +405,15 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
       const float4 rn = *reinterpret_cast<const float4*>(e->r_next + c);
       const float smv[4] = {sm.x, sm.y, sm.z, sm.w}, srv[4] = {sr.x, sr.y, sr.z, sr.w}, snv[4] = {sn.x, sn.y, sn.z, sn.w};
       const float rmv[4] = {rm.x, rm.y, rm.z, rm.w}, rnv[4] = {rn.x, rn.y, rn.z, rn.w};
+      const float4 mr = *reinterpret_cast<const float4*>(e->m128_sres + c);
+      const float mrv[4] = {mr.x, mr.y, mr.z, mr.w};
       float q3[4], xs[4];
       div_q8fx4<true>(y, smv, rmv, q3);                                // qact3 / mlp.qact2 (PTF) codes
+      // residual code * s_res with ONE rounding, from the biased byte: fma(u, s, -128 s) = RN((u - 128) s) = RN(code * s)
+      // (u*s is exact in the fma, -128*s is exact in fp32) -- v_cvt_f32_ubyteN + v_fma instead of bfe + cvt + mul
+      const unsigned ru = res[gq] ^ 0x80808080u;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xs[i] = (float)sx8(res[gq], i) * srv[i] + q3[i] * smv[i];   // x + dequantised branch
+      for (int i = 0; i < 4; ++i) xs[i] = __builtin_fmaf((float)((ru >> (8 * i)) & 255u), srv[i], mrv[i]) + q3[i] * smv[i];   // x + dequantised branch
       div_q8fx4<false>(xs, snv, rnv, q);                               // Block.qact2 / qact4 (PTF)
     } else if (EPI == P2V_EPI_EMBED) {
       const float4 sn = *reinterpret_cast<const float4*>(e->s_next + c);
@@ -1119,20 +1126,36 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < NI; ++i) wf[i] = __builtin_bit_cast(v4i, wsrc[i * 64]);
 
+  // ---- the 64 rows of the residual stream: one row per half wave, 8 rows each, every load requested up front
+  constexpr int RPH = LG_BM / 8;                                       // rows per half wave
+  const int hw = tid >> 5;
+  unsigned win[RPH][NCH];
+#pragma unroll
+  for (int r = 0; r < RPH; ++r) {
+    long long row = (long long)m0 + hw * RPH + r;
+    row = row < a.rows ? row : a.rows - 1;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (l31 + 32 * i) * 4;
+      win[r][i] = *reinterpret_cast<const unsigned*>(a.x + row * a.row_stride + (c < C ? c : 0));
+    }
+  }
   // ---- per-column constants of the whole layer (REQUANT: 2^e folded in, see gemm_stage_epilogue) and the GELU table
   {
     const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : 1.0f;
-    for (int n = tid; n < tiles_n * GBN; n += 256) {
-      const int j_ = n >> 7, c_ = n & (GBN - 1);
-      consts[j_ * 2 * GBN + c_] = g.colscale[n] * fold;               // arrays are padded to n_pad
-      consts[j_ * 2 * GBN + GBN + c_] = g.bias[n] * fold;
+    for (int n4 = tid; n4 < tiles_n * (GBN / 4); n4 += 256) {           // four columns per thread and turn
+      const int j_ = n4 >> 5, c_ = (n4 & 31) * 4;
+      const float4 cv = *reinterpret_cast<const float4*>(g.colscale + n4 * 4);   // arrays are padded to n_pad
+      const float4 bv = *reinterpret_cast<const float4*>(g.bias + n4 * 4);
+      *reinterpret_cast<float4*>(consts + j_ * 2 * GBN + c_) = make_float4(cv.x * fold, cv.y * fold, cv.z * fold, cv.w * fold);
+      *reinterpret_cast<float4*>(consts + j_ * 2 * GBN + GBN + c_) = make_float4(bv.x * fold, bv.y * fold, bv.z * fold, bv.w * fold);
     }
     if (EPI == P2V_EPI_GELU_TAB)
       for (int i = tid; i < cells; i += 256)
         reinterpret_cast<uint2*>(lg_smem + lay.table)[i] = reinterpret_cast<const uint2*>(g.ep.gelu.table)[i];
   }
   LG_STAMP(1);
-  // ---- LayerNorm of the 64 rows -> LDS panel (and, on request, HBM): one row per half wave, 8 rows each, all loads up front
+  // ---- LayerNorm -> LDS panel (and, on request, HBM)
   {
     float* sG = reinterpret_cast<float*>(lg_smem + lay.fold);
     float* sB = sG + NCH * 128;
@@ -1140,20 +1163,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
     int* sM = reinterpret_cast<int*>(sP + NCH * 128);
     LnLane<NCH> L;
     ln_prepare<NCH, 32>(a.ln, C, a.force_generic != 0, sG, sB, sP, sM, tid, 256, L);
-    const int hw = tid >> 5;
-    int colofs[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) colofs[i] = L.on[i] ? (l31 + 32 * i) * 4 : 0;
-    constexpr int RPH = LG_BM / 8;                                       // rows per half wave
-    unsigned win[RPH][NCH];
-#pragma unroll
-    for (int r = 0; r < RPH; ++r) {
-      long long row = (long long)m0 + hw * RPH + r;
-      row = row < a.rows ? row : a.rows - 1;
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) win[r][i] = *reinterpret_cast<const unsigned*>(a.x + row * a.row_stride + colofs[i]);
-    }
-#pragma unroll 1
+#pragma unroll 2
     for (int r = 0; r < RPH; ++r) {
       const int lrow = hw * RPH + r;
       unsigned wcur[NCH], outw[NCH];
@@ -1161,7 +1171,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
       for (int i = 0; i < NCH; ++i) {
         unsigned v = win[0][i];
 #pragma unroll
-        for (int rr = 1; rr < RPH; ++rr) v = r == rr ? win[rr][i] : v;   // register select: the row loop stays rolled (code size)
+        for (int rr = 1; rr < RPH; ++rr) v = r == rr ? win[rr][i] : v;   // register select: the row loop stays (mostly) rolled: code size
         wcur[i] = L.on[i] ? v : 0u;
       }
       ln_row<NCH, 32>(wcur, L, a.ln, C, l31, outw);
