@@ -33,6 +33,17 @@ class DataParallelForward:
         lo, hi = shard_bounds(global_images.shape[0], self.world, self.rank)
         return self.local(global_images[lo:hi], global_images.shape[0])
 
+    def _all_gather(self, gathered, shard):
+        """one all-gather on the tensors' own device (RCCL over xGMI for GPU tensors under backend "nccl").  The gloo backend of a
+        ROCm build has no device collectives: a GPU shard is then staged through the host (rehearsal runs of N ranks on one GPU)."""
+        if shard.is_cuda and dist.get_backend(self.group) == 'gloo':
+            host = torch.empty(gathered.shape, dtype=gathered.dtype)
+            dist.all_gather_into_tensor(host, shard.cpu(), group=self.group)
+            gathered.copy_(host)
+        else:
+            dist.all_gather_into_tensor(gathered, shard, group=self.group)
+        return gathered
+
     def local(self, local_images, global_n):
         out = self.fn(local_images)
         if self.world == 1:
@@ -41,12 +52,10 @@ class DataParallelForward:
         counts = [b - a for a, b in sizes]
         if len(set(counts)) == 1:
             gathered = torch.empty(global_n, self.num_classes, dtype=out.dtype, device=out.device)
-            dist.all_gather_into_tensor(gathered, out.contiguous(), group=self.group)
-            return gathered
+            return self._all_gather(gathered, out.contiguous())
         # ragged global batch: collectives need equal shapes, so pad every shard to the largest one
         cmax = max(counts)
         padded = torch.zeros(cmax, self.num_classes, dtype=out.dtype, device=out.device)
         padded[:out.shape[0]] = out
-        gathered = torch.empty(self.world * cmax, self.num_classes, dtype=out.dtype, device=out.device)
-        dist.all_gather_into_tensor(gathered, padded, group=self.group)
+        gathered = self._all_gather(torch.empty(self.world * cmax, self.num_classes, dtype=out.dtype, device=out.device), padded)
         return torch.cat([gathered[r * cmax: r * cmax + counts[r]] for r in range(self.world)], 0)

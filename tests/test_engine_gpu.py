@@ -798,3 +798,21 @@ def test_int_layernorm_kernel_vs_randomised_reference_vectors(dva):
         bad = int((got[finite] != want[finite]).sum())
         pot = bool((torch.frexp(out_scale)[0] == 0.5).all())
         assert bad == 0 or (not pot and bad <= 1), (i, bad, pot)
+
+
+def test_bench_two_ranks_on_one_gpu_gloo(dva):
+    """`python bench.py --gpus 2` as the driver invokes it (no torch.distributed environment): bench.py spawns the two ranks itself,
+    the step runs through dp.DataParallelForward, rank 0 prints one JSON line, and the gathered logits equal the two ranks'
+    own forwards.  Both ranks share device 0 (one-GPU box), so the collective runs on gloo instead of RCCL."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
+                        '--repeats', '2', '--batch', '12', '--model', 'deit_tiny', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak' and d['config']['global_batch'] == 24
+    assert d['config']['gathered_logits_equal_per_rank_forwards'] is True
+    assert d['value'] > 0 and 'roofline' in d and d['cpu_baseline'] is None
