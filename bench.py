@@ -204,7 +204,7 @@ def main():
     with torch.no_grad():                                 # fp32 teacher on the distinct images, before any calibration
         fp32_top1 = model(base.to(dev))[0].argmax(1).cpu()
     t_cal = time.perf_counter()
-    dva.harness.calibrate_model(model, dva.synth.images(SEED, 2, arch['img_size']).to(dev))
+    dva.harness.calibrate_model(model, dva.synth.images(SEED, 2, arch['img_size']).to(dev), where='host')    # exact exponents (harness.py)
     torch.cuda.synchronize()
     t_cal = time.perf_counter() - t_cal
     calib = model.export_calib()
@@ -354,7 +354,7 @@ def main():
             'model_mfma_frac': round(model_ops / (el / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
             'kernel_ms_per_step': breakdown,
             'cpu_baseline': cpu,
-            'calibration': {'seconds': round(t_cal, 2), 'device': 'gpu', 'tensors': len(ref_calib), 'tensors_bit_equal_reference': n_equal,
+            'calibration': {'seconds': round(t_cal, 2), 'device': 'host cpu (float pass + observer searches; harness.calibrate_model where=host)', 'tensors': len(ref_calib), 'tensors_bit_equal_reference': n_equal,
                             'scale_elements': n_elems, 'elements_off_by_a_power_of_two': exp_flips},
         }))
     if world > 1:

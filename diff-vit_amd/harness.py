@@ -44,6 +44,7 @@ def build_parser():
     p.add_argument('--synthetic', default=True, action='store_true', help='synthetic ImageNet-shaped data and random-init weights')
     p.add_argument('--n-val', default=500, type=int, help='number of synthetic validation images')
     p.add_argument('--bits', default=8, type=int, choices=[4, 8], help='uniform bit_config for the validation run')
+    p.add_argument('--calib-on', default='host', choices=['host', 'model'], help="where the calibration pass runs: 'host' reproduces the reference's exponents exactly")
     p.add_argument('--search-pop', default=25, type=int, help='--mixed: population size (test_quant.py:340)')
     p.add_argument('--search-iter', default=8, type=int, help='--mixed: evolutionary iterations (test_quant.py:343)')
     p.add_argument('--search-max-configs', default=50, type=int, help='--mixed: Pareto candidates kept (test_quant.py:281)')
@@ -112,15 +113,31 @@ def accuracy(output, target, topk=(1,)):
     return [correct[:k].reshape(-1).float().sum(0).mul_(100.0 / batch_size) for k in topk]
 
 
-def calibrate_model(model, calibrate_data):
+def calibrate_model(model, calibrate_data, where='host'):
     """the reference's calibration sequence (test_quant.py:235-249): one forward with calibrate + last_calibrate
-    open, then close and switch to quant."""
+    open, then close and switch to quant.
+
+    ``where='host'`` (default): the one-off float pass and the observers' power-of-two searches run on the host CPU, whatever device
+    the model lives on (it is moved there and back).  The searches pick the minimum of four nearly equal MSE scores per channel
+    (minmax.py:198-240, ptf.py:96-134); only the host path reproduces the reference's choices exponent for exponent (DeiT-S: 495 of
+    495 calibrated tensors, tests/test_module_surface.py and the GPU test of the same name), and the batched search makes it a
+    couple of seconds instead of the reference's minute.  ``where='model'`` runs everything on the model's device (GPU: faster
+    again, scores in fp64, but the float pass rounds differently there and a few hundred of 262 760 exponents move by one)."""
+    if where not in ('host', 'model'):
+        raise ValueError("where must be 'host' or 'model'")
+    dev = next(model.parameters()).device
+    on_host = where == 'host' and dev.type != 'cpu'
+    if on_host:
+        model.cpu()
+        calibrate_data = calibrate_data.cpu()
     model.model_open_calibrate()
     with torch.no_grad():
         model.model_open_last_calibrate()
         output, FLOPs, global_distance = _forward(model, calibrate_data)
     model.model_close_calibrate()
     model.model_quant()
+    if on_host:
+        model.to(dev)
     return output, FLOPs, global_distance
 
 
@@ -200,7 +217,7 @@ def main(argv=None):
     bit_config = None
     if args.quant:
         print('Calibrating with Gaussian noise...')
-        _, FLOPs, global_distance = calibrate_model(model, synth.images(args.seed + 1, args.calib_batchsize, arch['img_size']).to(device))
+        _, FLOPs, global_distance = calibrate_model(model, synth.images(args.seed + 1, args.calib_batchsize, arch['img_size']).to(device), where=args.calib_on)
         if args.mixed and not _is_swin(model):
             # test_quant.py:253-408 on the fast path: every candidate bit_config is one validate() over the HIP engine (the frozen
             # plan holds both weight widths per layer, so switching configurations costs nothing)

@@ -130,10 +130,11 @@ class MinmaxObserver(BaseObserver):
         red = [d for d in range(ref.dim()) if d != cdim]
         shape = [-1] + [1] * (w.dim() - 1)
         scores = []
+        acc = torch.float64 if ref.is_cuda else ref.dtype      # GPU runs: fp64 scores (the fp32 reduction order differs from the CPU's)
         for k in range(4):
             a = (alpha_floor - 1 + k).reshape(shape)
             wq = ((w / 2**a + zp).round().clamp(qmin, qmax) - zp) * 2**a
-            scores.append((ref - self._layer_out(wq, bias)).abs().pow(2.0).mean(dim=red))
+            scores.append((ref - self._layer_out(wq, bias)).to(acc).abs().pow(2.0).mean(dim=red))
         best = torch.stack(scores, 0).argmin(dim=0)            # first minimum on ties, like list.index(min(...))
         return alpha_floor - 1 + best.to(alpha_floor.dtype)
 

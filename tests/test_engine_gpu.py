@@ -414,7 +414,7 @@ def test_dropin_flow_matches_reference(dva, micro, calib_device):
     quantized forward (HIP engine) gives the reference's logits for all three bit configurations."""
     g = micro['g']
     m = _build_micro(dva, micro).to(calib_device)
-    out_cal, _, gd = dva.harness.calibrate_model(m, micro['x_cal'].to(calib_device))
+    out_cal, _, gd = dva.harness.calibrate_model(m, micro['x_cal'].to(calib_device), where='model')     # on calib_device itself
     assert np.abs(out_cal.cpu().numpy() - g['calib_logits']).max() <= 1e-4
     calib = m.export_calib()
     flat = dva.calib_io.flatten(calib)
@@ -445,6 +445,41 @@ def test_dropin_flow_matches_reference(dva, micro, calib_device):
     m.model_open_calibrate()
     assert m._plan is None
     m.model_close_calibrate()
+
+
+def test_deit_small_calibration_on_the_gpu_box(dva, oracle, synth):
+    """calibrate_model on a model that lives on the GPU (default where='host'): every power-of-two scale of DeiT-S equals the REAL
+    reference's (tests/golden/deit_small.npz) -- 0 exponents off -- and the PTF scales agree to 1e-5 with identical {1,2,4,8} factors.
+    The all-GPU path (where='model') is measured beside it: same tolerances for the float scales, a bounded number of exponent flips."""
+    g = load_golden('deit_small')
+    arch = synth.ARCHS['deit_small']
+    seed = int(g['seed'])
+    ref = {k[len('calib/'):]: g[k] for k in g.files if k.startswith('calib/')}
+    x = synth.images(seed, int(g['n_calib']), 224)
+
+    def run(where):
+        m = dva.deit_small_patch16_224(cfg=dva.Config(True, True, 'minmax'))
+        m.load_state_dict(synth.vit_state_dict(arch, seed), strict=False)
+        m = m.cuda().eval()
+        dva.harness.calibrate_model(m, x.cuda(), where=where)
+        assert next(m.parameters()).is_cuda
+        flat = dva.calib_io.flatten(m.export_calib())
+        flips = 0
+        for k, want in ref.items():
+            a = flat[k].numpy().reshape(want.shape)
+            if np.all(np.frexp(want)[0] == 0.5):
+                flips += int((a != want).sum())
+            else:
+                assert np.allclose(a, want, rtol=1e-5, atol=0), (where, k)
+                assert np.array_equal(np.round(a / a.min()), np.round(want / want.min())), (where, k)
+        return flips, m
+
+    flips, m = run('host')
+    assert flips == 0
+    out = m(synth.images(seed, 2, 224, offset=1000).cuda(), [8] * 50)[0]       # the frozen plan builds from host-side scales
+    assert out.shape == (2, 1000) and bool(torch.isfinite(out).all())
+    flips_gpu, _ = run('model')
+    assert flips_gpu <= 600, flips_gpu                                         # near ties of the per-channel search (262 760 scale elements)
 
 
 def test_module_level_quant_ops_on_gpu(dva):
