@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by RUNNING THE REAL REFERENCE (imported from /root/reference) on CPU.
 
-Run once in the build container:   python oracle/gen_golden.py [micro|deit_small|deit_tiny_fp|kat|all]
+Run once in the build container:   python oracle/gen_golden.py [micro|deit_small|deit_small_margin|deit_tiny_fp|kat|all]
 
 Nothing of the reference is copied: only its inputs and outputs (data) are stored.  The reference
 hard-codes ``.cuda()`` in its forward (e.g. models/vit_fquant.py:206, quantizer/uniform.py:85), which
@@ -111,17 +111,56 @@ def compare_oracle(tag, orc, x, bit_config, ref_out, ref_taps):
                 first_divergence=('%s:%d/%d' % worst[0]) if worst else 'none')
 
 
-def gen_model_fixture(name, arch, seed, n_calib, n_eval, store_weights, tap_filter, ref):
+def plant_head_margin(sd, arch, x_ev, extra, x_cal=None):
+    """DeiT-S 'margin' fixture: the synthetic head is given one planted class per evaluation image, so that the top-1 of every image
+    is separated from the runner-up by far more codes than the +-13 the platform-dependent roundings of the reference move a 4-bit
+    logit -- 'identical top-1 indices' (north_star) becomes testable at DeiT-S size.
+    The head input of image i is a 384-vector that differs between the float model and the three quantized configurations; the
+    planted rows delta solve  [F_float; F_q8; F_q4; F_qmix] @ delta^T = lambda * [I; I; I; I]  (minimum-norm solution, 4n << 384
+    equations), so image i gains lambda on class c_i and nothing on the other planted classes in all four models.  The quantized
+    features come from the oracle calibrated on the same batch (the head does not influence them).  The rows are stored in the
+    fixture (float passes differ by ulps between hosts); consumers add them to head.weight."""
+    orc = oracle.OracleViT(arch, sd)
+    n = x_ev.shape[0]
+    L = 4 * arch['depth'] + 2
+    mixed = [8 if (i * 7 + 3) % 5 < 3 else 4 for i in range(L)]
+    with torch.no_grad():
+        feats = [orc.float_features(x_ev)]
+        base = orc.float_forward(x_ev)
+        orc.calibrate(x_cal)
+        for bc in ([8] * L, [4] * L, mixed):
+            taps = {}
+            orc.quant_forward(x_ev, bc, taps)
+            feats.append(taps['qact2'].float().reshape(n, -1) * orc.calib['qact2'])
+    classes = torch.tensor([(37 + 113 * i) % arch['num_classes'] for i in range(n)])
+    lam = 3.0 * float(base.abs().max())
+    Fa = torch.cat(feats, 0).double()                                          # [4n, D]
+    T = lam * torch.eye(n, dtype=torch.float64).repeat(4, 1)                   # [4n, n]
+    delta = (torch.linalg.pinv(Fa) @ T).T.float()                              # [n, D]
+    sd = dict(sd)
+    hw = sd['head.weight'].clone()
+    hw[classes] += delta
+    sd['head.weight'] = hw
+    extra['head_classes'] = classes.numpy().astype(np.int64)
+    extra['head_delta'] = delta.numpy()
+    return sd
+
+
+def gen_model_fixture(name, arch, seed, n_calib, n_eval, store_weights, tap_filter, ref, sd_hook=None):
     t0 = time.time()
     sd = synth.vit_state_dict(arch, seed)
-    model = build_ref(arch, sd, ref)
     x_cal = synth.images(seed, n_calib, arch['img_size'])
     x_ev = synth.images(seed, n_eval, arch['img_size'], offset=1000)
+    extra = {}
+    if sd_hook is not None:
+        sd = sd_hook(sd, arch, x_ev, extra, x_cal)
+    model = build_ref(arch, sd, ref)
     L = 4 * arch['depth'] + 2
     mixed = [8 if (i * 7 + 3) % 5 < 3 else 4 for i in range(L)]
     cfgs = {'q8': [8] * L, 'q4': [4] * L, 'qmix': mixed}
     out = {'seed': np.int64(seed), 'n_calib': np.int64(n_calib), 'n_eval': np.int64(n_eval),
            'bit_qmix': np.array(mixed, dtype=np.int8)}
+    out.update(extra)
     with torch.no_grad():
         fp, flops, gd = model(x_ev)                   # float forward before any calibration
         out['fp_logits'] = fp.numpy()
@@ -272,6 +311,9 @@ def main():
     if what in ('deit_small', 'all'):
         keep = lambda n: n.startswith(('blocks.0.', 'blocks.11.')) or '.' not in n or n.startswith('patch_embed')
         gen_model_fixture('deit_small', synth.ARCHS['deit_small'], 3, 2, 4, False, keep, ref)
+    if what in ('deit_small_margin', 'all'):
+        # same architecture, seed 5, 8 evaluation images, a head with planted classes (plant_head_margin): top-1 testable at 4 bits
+        gen_model_fixture('deit_small_margin', synth.ARCHS['deit_small'], 5, 2, 8, False, lambda n: '.' not in n, ref, sd_hook=plant_head_margin)
 
 
 if __name__ == '__main__':

@@ -29,6 +29,13 @@ machine-independent reading, which the HIP kernels reproduce bit for bit:
 Pinning: ``oracle/gen_golden.py`` imports the real reference in the build container and stores its
 inputs/outputs in ``tests/golden``; ``tests/test_oracle_golden.py`` checks this file against them and
 reports the (tiny) mismatch the canonical reading introduces.
+
+The decomposition is executable: ``OracleViT(..., imitate={'linear', 'gelu', 'lis', 'ln'})`` swaps each canonical piece back
+for the torch-CPU operation the reference calls at that place (``F.linear``/``F.conv2d`` with the bias inside, ``F.gelu``, the
+all-fp32 ``int_softmax`` with its fp32 ``sum``, the fp32 LayerNorm statistics with ``torch.sqrt``/``log2``/``pow``).  With all
+four the oracle is the reference as run in this container, bit for bit, also at DeiT-S size
+(``tests/test_oracle_golden.py::test_deit_small_decomposition``); with one of them left canonical the first differing tap is the
+one DESIGN.md section 2 names.
 """
 import math
 
@@ -261,6 +268,25 @@ def int_layernorm(x, in_scale, gamma, beta, out_scale):
     return ((sign * M * x_q + B) / pN).round()
 
 
+def int_layernorm_torchcpu(x, in_scale, gamma, beta, out_scale):
+    """QIntLayerNorm.forward mode 'int' with the reference's own fp32 torch ops (layers.py:234-238, 255-289): fp32 ``sum`` /
+    ``mean`` of integers above 2^24, ``torch.sqrt``, ``torch.log2``, ``torch.pow`` -- platform-dependent roundings included.
+    Used only by ``imitate={'ln'}``."""
+    C = x.shape[-1]
+    in_scale = in_scale.reshape(1, 1, -1)
+    out_scale = out_scale.reshape(1, 1, -1)
+    x_q = (x / in_scale).round()
+    s1 = in_scale.min()
+    x_q = x_q * (in_scale / s1).round()
+    mean = x_q.mean(dim=-1) * s1
+    std = (s1 / C) * torch.sqrt(C * (x_q**2).sum(dim=-1) - x_q.sum(dim=-1)**2)
+    A = (s1 / std).unsqueeze(-1) * gamma.reshape(1, 1, -1) / out_scale
+    N = torch.clamp(7 - torch.floor(torch.log2(A.abs())), 0, 31)
+    M = torch.clamp(torch.floor(A.abs() * torch.pow(2, N)), 0, 255)
+    B = ((beta.reshape(1, 1, -1) - (mean / std).unsqueeze(-1) * gamma.reshape(1, 1, -1)) / out_scale * torch.pow(2, N)).round()
+    return ((A.sign() * M * x_q + B) / torch.pow(2, N)).round()
+
+
 def gelu_rn(y):
     """correctly-rounded fp32 GELU (reference: float nn.GELU, layers_quant.py:147,331)."""
     yd = y.double()
@@ -289,16 +315,46 @@ def qgemm(x_codes, s_x, w_codes, s_w, bias):
 class OracleViT:
     """Functional ViT/DeiT: weights are a timm-style state_dict, calibration state is a flat dict."""
 
-    def __init__(self, arch, state_dict, in_chans=3, ln_eps=1e-6):
+    IMITATE = ('linear', 'gelu', 'lis', 'ln')
+
+    def __init__(self, arch, state_dict, in_chans=3, ln_eps=1e-6, imitate=()):
         self.a = dict(arch)
         self.W = {k: v.detach().float() for k, v in state_dict.items()}
         self.in_chans = in_chans
         self.ln_eps = ln_eps
         self.calib = None
         self.global_distance = []
+        # which canonical pieces of quant_forward are swapped back for the torch-CPU op the reference calls (module docstring)
+        self.imitate = frozenset(imitate)
+        assert self.imitate <= set(self.IMITATE), self.imitate
+
+    # ----- the four places where the reference's result depends on the machine ---------------------------
+    def _linear(self, x_codes, s_x, w_codes, s_w, bias):
+        if 'linear' in self.imitate:       # F.linear on the fake-quantised fp32 operands, bias inside (layers.py:178)
+            return F.linear(x_codes * s_x, w_codes * s_w.reshape(-1, 1), bias)
+        return qgemm(x_codes, s_x, w_codes, s_w, bias)
+
+    def _gelu(self, y):
+        return F.gelu(y) if 'gelu' in self.imitate else gelu_rn(y)      # nn.GELU (layers_quant.py:147,331)
+
+    def _lis_k(self, codes, sf):
+        if 'lis' in self.imitate:          # the all-fp32 int_softmax incl. its fp32 sum (layers.py:331-376)
+            p = lis_float(codes * sf, sf)
+            return torch.where(p > 0, -torch.log2(p.clamp(min=1e-30)), torch.full_like(p, 16.0)).round().to(torch.int64)
+        return lis_int(codes, sf)
+
+    def _ln(self, x, in_scale, gamma, beta, out_scale):
+        return (int_layernorm_torchcpu if 'ln' in self.imitate else int_layernorm)(x, in_scale, gamma, beta, out_scale)
+
+    def float_features(self, x):
+        """the float model's input to the head (final norm, cls row): used by oracle/gen_golden.py to plant class margins."""
+        return self._float_trunk(x)
 
     # ----- plain float forward (bit-for-bit what the reference computes before any calibration) ------
     def float_forward(self, x):
+        return F.linear(self._float_trunk(x), self.W['head.weight'], self.W['head.bias'])
+
+    def _float_trunk(self, x):
         W, a = self.W, self.a
         D, H = a['embed_dim'], a['num_heads']
         x = F.conv2d(x, W['patch_embed.proj.weight'], W['patch_embed.proj.bias'], a['patch_size'])
@@ -313,8 +369,7 @@ class OracleViT:
             h = F.linear(F.gelu(F.linear(h, W[p + 'mlp.fc1.weight'], W[p + 'mlp.fc1.bias'])),
                          W[p + 'mlp.fc2.weight'], W[p + 'mlp.fc2.bias'])
             x = x + h
-        x = F.layer_norm(x, (D,), W['norm.weight'], W['norm.bias'], self.ln_eps)[:, 0]
-        return F.linear(x, W['head.weight'], W['head.bias'])
+        return F.layer_norm(x, (D,), W['norm.weight'], W['norm.bias'], self.ln_eps)[:, 0]
 
     def _attn_float(self, h, p, H):
         W = self.W
@@ -466,9 +521,13 @@ class OracleViT:
         wq = weight_codes(W['patch_embed.proj.weight'], None, s_w, bit)
         P = a['patch_size']
         Bn = x.shape[0]
-        cols = F.unfold(q, kernel_size=P, stride=P).transpose(1, 2)          # [B, patches, C*P*P]
-        y = qgemm(cols.reshape(-1, cols.shape[-1]), s_in, wq, s_w.reshape(-1), W['patch_embed.proj.bias'])
-        y = y.reshape(Bn, -1, D)
+        if 'linear' in self.imitate:       # F.conv2d on the fake-quantised operands (layers.py:87)
+            y = F.conv2d(q * s_in, (wq * s_w.reshape(-1, 1)).reshape(W['patch_embed.proj.weight'].shape), W['patch_embed.proj.bias'], stride=P)
+            y = y.flatten(2).transpose(1, 2)
+        else:
+            cols = F.unfold(q, kernel_size=P, stride=P).transpose(1, 2)          # [B, patches, C*P*P]
+            y = qgemm(cols.reshape(-1, cols.shape[-1]), s_in, wq, s_w.reshape(-1), W['patch_embed.proj.bias'])
+            y = y.reshape(Bn, -1, D)
         s_pe = c['patch_embed.qact']
         xv = q8(y, s_pe) * s_pe
         tap('patch_embed.qact', q8(y, s_pe))
@@ -491,13 +550,13 @@ class OracleViT:
             cs = c[p + 'attn.best_scale'][bi]
             s_a0 = c[p + 'attn.best_act_scale'][bi]
             s_wq = c[p + 'attn.best_weight_scale'][bi]['int%d' % bits[0]]
-            ln = int_layernorm(xv, s_res, W[p + 'norm1.weight'], W[p + 'norm1.bias'], s_a0 * cs)
+            ln = self._ln(xv, s_res, W[p + 'norm1.weight'], W[p + 'norm1.bias'], s_a0 * cs)
             h = ln * (s_a0 * cs).reshape(1, 1, -1)
             q0 = q8(h / cs.reshape((1, 1, -1)), s_a0)
             tap(p + 'attn.qact0', q0)
             wq = weight_codes(W[p + 'attn.qkv.weight'], cs, s_wq, bits[0])
             N = q0.shape[1]
-            y = qgemm(q0.reshape(-1, D), s_a0, wq, s_wq.reshape(-1), W[p + 'attn.qkv.bias']).reshape(Bn, N, 3 * D)
+            y = self._linear(q0.reshape(-1, D), s_a0, wq, s_wq.reshape(-1), W[p + 'attn.qkv.bias']).reshape(Bn, N, 3 * D)
             s_q1 = c[p + 'attn.qact1']
             q1 = q8(y, s_q1)
             tap(p + 'attn.qact1', q1)
@@ -507,7 +566,7 @@ class OracleViT:
             s_at = c[p + 'attn.qact_attn1']
             sc = q8(attn, s_at)
             tap(p + 'attn.qact_attn1', sc)
-            k = lis_int(sc, s_at)
+            k = self._lis_k(sc, s_at)
             tap(p + 'attn.softmax_k', k)
             o = (lis_probs(k) @ (qkv[2] * s_q1)).transpose(1, 2).reshape(Bn, N, D)   # exact (dyadic sums)
             s_a2 = c[p + 'attn.qact2']
@@ -515,7 +574,7 @@ class OracleViT:
             tap(p + 'attn.qact2', q2)
             s_wp = c[p + 'attn.proj']['int%d' % bits[1]]
             wq = weight_codes(W[p + 'attn.proj.weight'], None, s_wp, bits[1])
-            y = qgemm(q2.reshape(-1, D), s_a2, wq, s_wp.reshape(-1), W[p + 'attn.proj.bias']).reshape(Bn, N, D)
+            y = self._linear(q2.reshape(-1, D), s_a2, wq, s_wp.reshape(-1), W[p + 'attn.proj.bias']).reshape(Bn, N, D)
             s_a3 = c[p + 'attn.qact3'].reshape(1, 1, -1)
             q3 = q8(y, s_a3)
             tap(p + 'attn.qact3', q3)
@@ -529,18 +588,18 @@ class OracleViT:
             cs_m = c[p + 'mlp.best_scale'][bm]
             s_m0 = c[p + 'mlp.best_act_scale'][bm]
             s_w1 = c[p + 'mlp.best_weight_scale'][bm]['int%d' % bits[2]]
-            ln = int_layernorm(xv, s_res, W[p + 'norm2.weight'], W[p + 'norm2.bias'], s_m0 * cs)
+            ln = self._ln(xv, s_res, W[p + 'norm2.weight'], W[p + 'norm2.bias'], s_m0 * cs)
             h = ln * (s_m0 * cs).reshape(1, 1, -1)
             q0 = q8(h / cs_m.reshape((1, 1, -1)), s_m0)
             tap(p + 'mlp.qact0', q0)
             wq = weight_codes(W[p + 'mlp.fc1.weight'], cs_m, s_w1, bits[2])
-            y = qgemm(q0.reshape(-1, D), s_m0, wq, s_w1.reshape(-1), W[p + 'mlp.fc1.bias'])
+            y = self._linear(q0.reshape(-1, D), s_m0, wq, s_w1.reshape(-1), W[p + 'mlp.fc1.bias'])
             s_m1 = c[p + 'mlp.qact1']
-            q1 = q8(gelu_rn(y), s_m1)
+            q1 = q8(self._gelu(y), s_m1)
             tap(p + 'mlp.qact1', q1.reshape(Bn, N, -1))
             s_w2 = c[p + 'mlp.fc2']['int%d' % bits[3]]
             wq = weight_codes(W[p + 'mlp.fc2.weight'], None, s_w2, bits[3])
-            y = qgemm(q1, s_m1, wq, s_w2.reshape(-1), W[p + 'mlp.fc2.bias']).reshape(Bn, N, D)
+            y = self._linear(q1, s_m1, wq, s_w2.reshape(-1), W[p + 'mlp.fc2.bias']).reshape(Bn, N, D)
             s_m2 = c[p + 'mlp.qact2'].reshape(1, 1, -1)
             q2 = q8(y, s_m2)
             tap(p + 'mlp.qact2', q2)
@@ -552,13 +611,13 @@ class OracleViT:
 
         # final norm (cls row only is consumed), qact2, head, act_out        vit_fquant.py:766-796
         s_f = c['qact2']
-        ln = int_layernorm(xv[:, :1], s_res, W['norm.weight'], W['norm.bias'], s_f.expand(D))
+        ln = self._ln(xv[:, :1], s_res, W['norm.weight'], W['norm.bias'], s_f.expand(D))
         qf = q8(ln[:, 0] * s_f, s_f)
         tap('qact2', qf)
         bit = bit_config[-1]
         s_wh = c['head']['int%d' % bit]
         wq = weight_codes(W['head.weight'], None, s_wh, bit)
-        y = qgemm(qf, s_f, wq, s_wh.reshape(-1), W['head.bias'])
+        y = self._linear(qf, s_f, wq, s_wh.reshape(-1), W['head.bias'])
         s_o = c['act_out']
         ql = q8(y, s_o)
         tap('act_out', ql)

@@ -54,5 +54,15 @@ def micro(oracle, synth):
                 x_cal=torch.from_numpy(g['x_cal']), x_ev=torch.from_numpy(g['x_ev']))
 
 
+def planted_state_dict(g, synth_mod, arch):
+    """weights of a fixture generated with oracle/gen_golden.py::plant_head_margin: the seeded synthetic model plus the stored
+    head rows (one planted class per evaluation image)."""
+    sd = synth_mod.vit_state_dict(arch, int(g['seed']))
+    hw = sd['head.weight'].clone()
+    hw[torch.from_numpy(g['head_classes'])] += torch.from_numpy(g['head_delta'])
+    sd['head.weight'] = hw
+    return sd
+
+
 def gpu_ok():
     return torch.cuda.is_available()

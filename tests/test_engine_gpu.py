@@ -105,6 +105,26 @@ def test_deit_small_vs_oracle_and_golden(dva, oracle, synth):
             assert np.array_equal(got, taps[name].reshape(B * T, cols).numpy().astype(np.int64)), (tag, name)
 
 
+def test_deit_small_margin_top1_identical_on_gpu(dva, oracle, synth):
+    """the HIP engine on the planted-margin DeiT-S fixture (tests/golden/deit_small_margin.npz): logits bit-equal to the canonical
+    oracle, and top-1 IDENTICAL to the real reference's on all 8 images for [8]*50, [4]*50 and the mixed list."""
+    from conftest import planted_state_dict
+    g = load_golden('deit_small_margin')
+    arch = synth.ARCHS['deit_small']
+    sd = planted_state_dict(g, synth, arch)
+    calib = golden_calib(g, oracle)
+    plan = dva.FrozenPlan(arch, sd, calib)
+    x = synth.images(int(g['seed']), int(g['n_eval']), 224, offset=1000)
+    orc = oracle.OracleViT(arch, sd)
+    orc.calib = calib
+    for tag in ('q8', 'q4', 'qmix'):
+        bits = _bits(g, tag, 50)
+        out = plan.forward(x.cuda(), bits).cpu()
+        assert torch.equal(out, orc.quant_forward(x, bits)), tag
+        assert np.array_equal(out.argmax(1).numpy(), g['logits/' + tag].argmax(1)), tag
+        assert np.array_equal(out.argmax(1).numpy(), g['head_classes']), tag
+
+
 def test_deit_small_full_batch_properties(dva, oracle, synth):
     """BASELINE config 2 at its full size (batch 256): size-independent properties instead of a 256-image CPU oracle run -
     (a) the 4 oracle-checked images keep their logits at any position of a 256-image batch and in either stream slice,
