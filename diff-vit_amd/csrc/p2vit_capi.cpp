@@ -220,7 +220,8 @@ struct Prof {
 };
 
 static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
-                        size_t workspace_bytes, int stop_after, void* stream, Prof* prof) {
+                        size_t workspace_bytes, int stop_after, void* stream, Prof* prof, float* const* qkv_tap = nullptr,
+                        float* const* fc1_tap = nullptr) {
   if (!p || !images || !bit_config || !logits || !workspace) return fail(P2V_E_ARG, "p2v_forward: null argument");
   if (batch <= 0) return fail(P2V_E_SHAPE, "batch must be positive");
   if (n_cfg != p->n_layers) return fail(P2V_E_BITS, "bit_config has %d entries, model needs %d", n_cfg, p->n_layers);
@@ -275,6 +276,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     // qkv -> qact1                                                          vit_fquant.py:293,307
     p2v_epilogue e{};
     e.inv_s_out = b.inv_s_qkv[bq];
+    e.tap_out = qkv_tap ? qkv_tap[i] : nullptr;
     if (p->lin[bq][1 + 4 * i].w_frag && p2v_ln_gemm_supported(P2V_EPI_REQUANT, D, 3 * D, 0)) {              // one launch: the LayerNorm output stays in LDS
       if (!taps) ln.out = nullptr;
       STEP(P2V_K_LN_GEMM_QKV, run_ln_gemm(P2V_EPI_REQUANT, ln, p->lin[bq][1 + 4 * i], e, 3 * D, bufQKV, st));
@@ -295,6 +297,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     p2v_epilogue e1{};
     e1.inv_s_out = b.inv_s_fc1;
     e1.gelu = b.gelu_fc1;
+    e1.tap_out = fc1_tap ? fc1_tap[i] : nullptr;
     if (p->lin[b1][3 + 4 * i].w_frag && p2v_ln_gemm_supported(P2V_EPI_GELU, D, Hd, e1.gelu.table ? e1.gelu.cells : 0)) {
       if (!taps) ln2.out = nullptr;
       STEP(P2V_K_LN_GEMM_FC1, run_ln_gemm(P2V_EPI_GELU, ln2, p->lin[b1][3 + 4 * i], e1, Hd, bufHID, st));
@@ -328,6 +331,11 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
 int p2v_forward(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
                 size_t workspace_bytes, int stop_after, void* stream) {
   return forward_impl(p, images, batch, bit_config, n_cfg, logits, workspace, workspace_bytes, stop_after, stream, nullptr);
+}
+
+int p2v_forward_taps(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
+                     size_t workspace_bytes, float* const* qkv_out, float* const* fc1_out, void* stream) {
+  return forward_impl(p, images, batch, bit_config, n_cfg, logits, workspace, workspace_bytes, -1, stream, nullptr, qkv_out, fc1_out);
 }
 
 int p2v_forward_profile(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,

@@ -386,6 +386,11 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
     y[1] = __builtin_fmaf((float)acc[4 * gq + 1], cs.y, bs.y);
     y[2] = __builtin_fmaf((float)acc[4 * gq + 2], cs.z, bs.z);
     y[3] = __builtin_fmaf((float)acc[4 * gq + 3], cs.w, bs.w);
+    if ((EPI == P2V_EPI_REQUANT || EPI == P2V_EPI_GELU || EPI == P2V_EPI_GELU_TAB) && g.ep.tap_out && row_ok && n < g.N) {
+      // activation tap (qkv_output / fc1_output): the fp32 layer output.  REQUANT carries 2^e in its constants: undo it exactly
+      const float un = EPI == P2V_EPI_REQUANT ? 1.0f / g.ep.inv_s_out : 1.0f;
+      *reinterpret_cast<float4*>(g.ep.tap_out + (long long)m * g.N + n) = make_float4(y[0] * un, y[1] * un, y[2] * un, y[3] * un);
+    }
     float q[4];                 // integral floats; the byte packing below saturates to [-128,127]
     if (EPI == P2V_EPI_GELU_TAB) {
       d[gq] = gelu_tab_q8x4<ASM_LDS>(y, gtab, g.ep.gelu.k, g.ep.gelu.off, (float)(g.ep.gelu.cells - 1));

@@ -50,7 +50,8 @@ class GeluTab(C.Structure):
 
 class Epilogue(C.Structure):
     _fields_ = [('inv_s_out', _f), ('s_out', _f), ('s_mid', _p), ('s_res', _p), ('s_next', _p), ('residual', _p),
-                ('inv_s_pe', _f), ('pe_to_embed', _f), ('s_embed', _f), ('pos_deq', _p), ('patches', _i), ('gelu', GeluTab)]
+                ('inv_s_pe', _f), ('pe_to_embed', _f), ('s_embed', _f), ('pos_deq', _p), ('patches', _i), ('gelu', GeluTab),
+                ('tap_out', _p)]
 
 
 class Block(C.Structure):
@@ -102,6 +103,7 @@ def lib():
     L.p2v_workspace_view.argtypes = [_p, _i, C.c_char_p]
     L.p2v_workspace_view.restype = _ll
     L.p2v_forward.argtypes = [_p, _p, _i, C.POINTER(C.c_int8), _i, _p, _p, C.c_size_t, _i, _p]
+    L.p2v_forward_taps.argtypes = [_p, _p, _i, C.POINTER(C.c_int8), _i, _p, _p, C.c_size_t, C.POINTER(_p), C.POINTER(_p), _p]
     L.p2v_forward_profile.argtypes = [_p, _p, _i, C.POINTER(C.c_int8), _i, _p, _p, C.c_size_t, _p, C.POINTER(C.c_float),
                                       C.POINTER(C.c_int32), _i]
     L.p2v_quantize_patchify.argtypes = [_p, _i, _i, _i, _i, _i, _f, _p, _i, _p]

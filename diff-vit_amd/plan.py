@@ -250,16 +250,28 @@ class FrozenPlan:
         cfg = (C.c_int8 * len(bit_config))(*[int(b) if -128 <= int(b) <= 127 else 127 for b in bit_config])
         return images.contiguous().float(), cfg
 
-    def forward(self, images, bit_config, stop_after=-1, out=None):
-        """images: fp32 [B,C,H,W] on the plan's device -> fp32 logits [B, classes] (int8 grid * act_out scale)."""
+    def forward(self, images, bit_config, stop_after=-1, out=None, taps=None):
+        """images: fp32 [B,C,H,W] on the plan's device -> fp32 logits [B, classes] (int8 grid * act_out scale).
+        ``taps`` (dict): filled with 'qkv_output' / 'fc1_output' -> list of fp32 [B, tokens, 3D] / [B, tokens, hidden] tensors per
+        block, the layer outputs before qact1 / GELU that the reference keeps for its analysis scripts (vit_fquant.py:301,
+        layers_quant.py:326); written by the GEMM epilogues of the same launches."""
         images, cfg = self._check(images, bit_config)
         B = images.shape[0]
         with torch.cuda.device(self.device):
             ws = self.workspace(B)
             if out is None:
                 out = torch.empty(B, self.arch['num_classes'], dtype=torch.float32, device=self.device)
-            E.check(E.lib().p2v_forward(self._handle, E.ptr(images), B, cfg, len(bit_config), E.ptr(out), E.ptr(ws),
-                                        ws.numel(), stop_after, E.stream_ptr(self.device)))
+            if taps is None:
+                E.check(E.lib().p2v_forward(self._handle, E.ptr(images), B, cfg, len(bit_config), E.ptr(out), E.ptr(ws),
+                                            ws.numel(), stop_after, E.stream_ptr(self.device)))
+            else:
+                qkv = [torch.empty(B, self.tokens, 3 * self.D, dtype=torch.float32, device=self.device) for _ in range(self.depth)]
+                fc1 = [torch.empty(B, self.tokens, self.hidden, dtype=torch.float32, device=self.device) for _ in range(self.depth)]
+                pq = (C.c_void_p * self.depth)(*[t.data_ptr() for t in qkv])
+                pf = (C.c_void_p * self.depth)(*[t.data_ptr() for t in fc1])
+                E.check(E.lib().p2v_forward_taps(self._handle, E.ptr(images), B, cfg, len(bit_config), E.ptr(out), E.ptr(ws), ws.numel(),
+                                                 pq, pf, E.stream_ptr(self.device)))
+                taps['qkv_output'], taps['fc1_output'] = qkv, fc1
         return out
 
     def forward_streams(self, images, bit_config, out, n_streams=2):

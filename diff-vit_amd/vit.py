@@ -89,8 +89,9 @@ class _SmoothQuantMixin:
             return gt
         i = bit_pool.index(bit_config)                      # ValueError for widths outside the pool
         self.channel_scale = self.best_scale[i]
-        x_s = x / self.channel_scale.reshape((1, 1, -1))
-        w_s = lin.weight * self.channel_scale.reshape((1, -1))
+        cs = self.channel_scale.to(x.device)                # the calibrated state may live on the host (calibrate_model where='host')
+        x_s = x / cs.reshape((1, 1, -1))
+        w_s = lin.weight * cs.reshape((1, -1))
         qact0.quantizer.scale = self.best_act_scale[i]
         qact0.quantizer.zero_point = self.best_act_zp[i]
         lin.quantizer.dic_scale = self.best_weight_scale[i]
@@ -314,6 +315,8 @@ class VisionTransformer(nn.Module):
         self.apply(self._init_weights)
         self._plan = None
         self._qmods = None
+        self._lnmods = None
+        self.capture_taps = False      # True: quantized forwards also fill blocks[i].attn.qkv_output / .mlp.fc1_output (fp32)
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
@@ -377,6 +380,8 @@ class VisionTransformer(nn.Module):
                                       'patch-embed convolution: not an integer pipeline, not part of the fused engine')
 
         def sc(q):
+            if q.quantizer.scale is None:
+                raise RuntimeError('the model has not been calibrated: run the calibration sequence (harness.calibrate_model) before a quantized forward')
             return q.quantizer.scale.detach().float().cpu()
 
         def dic(l):
@@ -452,23 +457,33 @@ class VisionTransformer(nn.Module):
     def _fused(self):
         """the fused engine replaces the module-by-module graph only in the state ``model_quant()`` leaves behind: the model
         flag AND every Q-module's own ``.quant`` set (the reference's forward reads the per-module flags, so
-        ``model_dequant()`` or a single ``m.quant = False`` sends it down the float branch of that module)."""
-        return self.quant and all(m.quant and not m.calibrate for m in self._q_modules())
+        ``model_dequant()`` or a single ``m.quant = False`` sends it down the float branch of that module) AND every
+        QIntLayerNorm still in mode 'int' (a ``-1`` entry flips its block's norm to float for good, vit_fquant.py:429-430)."""
+        if self._lnmods is None:
+            self._lnmods = [m for m in self.modules() if type(m) is QIntLayerNorm]
+        return (self.quant and all(m.quant and not m.calibrate for m in self._q_modules())
+                and all(m.mode == 'int' for m in self._lnmods))
 
     def forward(self, x, bit_config=None, plot=False, hessian_statistic=False):
-        if self._fused() and not hessian_statistic:
+        # bit_config == -1 is the reference's per-layer fp32 fallback (layers.py:144,171: plain F.linear / F.conv2d; for qkv / fc1
+        # the SmoothQuant branch `channel_scale == None or bit_config == -1`, vit_fquant.py:199, layers_quant.py:222; the block's
+        # norm flips to F.layer_norm, vit_fquant.py:429-430,462-463).  Such a model is partly float by request: it runs the module
+        # graph below, as in the reference, not the integer engine.
+        has_fp = bit_config is not None and any(int(b) == -1 for b in bit_config)
+        if self._fused() and not hessian_statistic and not has_fp:
             # ---- THE HOT PATH: fused HIP engine -----------------------------------------------------------------
             if bit_config is None:
                 raise ValueError('None is not in list')          # bit_pool.index(None), vit_fquant.py:282
-            if any(int(b) == -1 for b in bit_config[1:-1]):
-                # the reference looks the block's bit up in bit_pool before anything else (vit_fquant.py:282, layers_quant.py
-                # SmoothQuant lookup): -1 raises there too (its own comments note the -1 path ends in NaN, vit_fquant.py:465-466)
-                raise ValueError('-1 is not in list')
-            if int(bit_config[0]) == -1 or int(bit_config[-1]) == -1:
-                raise NotImplementedError('fp32 patch-embed / head (bit_config == -1, layers.py:144,171) is not part of the fused engine')
             if self._plan is None:
                 self.freeze(x.device if x.is_cuda else None)
-            return self._plan.forward(x, [int(b) for b in bit_config]), self.flops(), []
+            if not self.capture_taps:
+                return self._plan.forward(x, [int(b) for b in bit_config]), self.flops(), []
+            # activation taps for the analysis scripts (cka_utility.py:44-47): written by the GEMM epilogues of the same launches
+            taps = {}
+            out = self._plan.forward(x, [int(b) for b in bit_config], taps=taps)
+            for blk, tq, tf in zip(self.blocks, taps['qkv_output'], taps['fc1_output']):
+                blk.attn.qkv_output, blk.mlp.fc1_output = tq, tf
+            return out, self.flops(), []
         FLOPs, global_distance = [], []
         x = self.forward_features(x, FLOPs, global_distance, bit_config, plot, hessian_statistic)
         B, C = x.shape

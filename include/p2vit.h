@@ -126,6 +126,9 @@ typedef struct p2v_epilogue {
   const float* pos_deq;  /* dev [tokens][N]  qact_pos(pos_embed), dequantised                 */
   int32_t patches;       /* patches per image; output row = b*(patches+1) + 1 + p             */
   p2v_gelu_tab gelu;     /* GELU only: threshold table for inv_s_out (optional)              */
+  float* tap_out;        /* REQUANT/GELU, optional: dev fp32 [M][N] receives the layer output BEFORE the
+                            following QAct / GELU, acc*colscale + bias -- what the reference keeps as
+                            Attention.qkv_output (vit_fquant.py:301) / Mlp.fc1_output (layers_quant.py:326) */
 } p2v_epilogue;
 
 typedef struct p2v_plan p2v_plan;
@@ -166,6 +169,13 @@ size_t p2v_workspace_bytes(const p2v_plan* plan, int batch);
  * that many kernel launches (parity tests read the workspace buffers, see p2v_workspace_view). */
 int p2v_forward(p2v_plan* plan, const float* images, int batch, const int8_t* bit_config, int n_cfg,
                 float* logits, void* workspace, size_t workspace_bytes, int stop_after, void* stream);
+
+/* p2v_forward with the activation taps of the analysis scripts (cka_utility.py:26-113 reads blocks[i].attn.qkv_output and
+ * blocks[i].mlp.fc1_output): qkv_out / fc1_out are HOST arrays of `depth` device pointers (entries or the arrays themselves may be
+ * NULL); entry i receives fp32 [batch*tokens][3*embed_dim] / [batch*tokens][mlp_hidden] of block i. */
+int p2v_forward_taps(p2v_plan* plan, const float* images, int batch, const int8_t* bit_config, int n_cfg,
+                     float* logits, void* workspace, size_t workspace_bytes, float* const* qkv_out, float* const* fc1_out,
+                     void* stream);
 
 /* Kernel kinds reported by p2v_forward_profile. */
 enum {

@@ -166,23 +166,22 @@ def test_local_checkpoint_ingestion(tmp_path, synth):
         checkpoint.load_checkpoint(mk(), str(tmp_path / 'bad.pth'))
 
 
-def test_minus_one_bit_config_error_convention(synth):
-    """bit_config == -1 in a block position raises ValueError before any engine call, like bit_pool.index(-1) does in the
-    reference (vit_fquant.py:282); -1 for the patch embed / head is NotImplementedError (no fp32 layer in the fused engine)."""
+def test_bit_config_error_conventions(synth):
+    """an uncalibrated model in quant state: bit_config None raises ValueError before any engine call, like bit_pool.index(None) in the
+    reference (vit_fquant.py:282); a width outside the pool raises KeyError from the BIT_TYPE_DICT lookup (layers.py:174-175) once a -1
+    entry has sent the forward down the module graph (see test_bit_config_minus_one_is_the_reference_fp_fallback for -1 itself)."""
     import diff_vit_amd as dva
     arch = synth.ARCHS['micro']
     m = dva.VisionTransformer(img_size=arch['img_size'], patch_size=arch['patch_size'], embed_dim=arch['embed_dim'], depth=arch['depth'],
                               num_heads=arch['num_heads'], num_classes=arch['num_classes'], mlp_ratio=arch['mlp_ratio'], qkv_bias=True,
-                              cfg=dva.Config(True, True, 'minmax')).eval()
+                              input_quant=True, cfg=dva.Config(True, True, 'minmax')).eval()
     m.model_quant()
     x = torch.zeros(1, 3, arch['img_size'], arch['img_size'])
     L = 4 * arch['depth'] + 2
     with pytest.raises(ValueError):
-        m(x, [8, -1] + [8] * (L - 2))
-    with pytest.raises(NotImplementedError):
-        m(x, [-1] + [8] * (L - 1))
-    with pytest.raises(ValueError):
         m(x, None)
+    with pytest.raises(RuntimeError):
+        m(x, [8] * L)                       # all-quantized on a CPU tensor: the engine refuses (no fallback)
 
 
 def test_qintlayernorm_module_vs_randomised_reference_vectors():
@@ -264,3 +263,31 @@ def test_model_dequant_leaves_the_fused_path_like_the_reference(dva, micro):
     s_o = float(m.act_out.quantizer.scale)
     assert np.abs(out.numpy() - gd['fc2_float/q8']).max() <= 1.01 * s_o
     assert float((out.numpy() == gd['fc2_float/q8']).mean()) > 0.9
+
+
+def test_bit_config_minus_one_is_the_reference_fp_fallback(dva, micro):
+    """bit_config entries of -1 (per-layer fp32 fallback: layers.py:144,171; vit_fquant.py:199,429-430; layers_quant.py:222) run the
+    module graph like the reference -- never the integer engine, never an error -- and flip the block's QIntLayerNorm to float for
+    good, after which even [8]*10 stays on the module graph.  Expected logits: the REAL reference (tests/golden/
+    micro_vit_fp_fallback.npz, oracle/gen_golden_fp_fallback.py).  CPU: the engine is not involved."""
+    from conftest import load_golden
+    gf = load_golden('micro_vit_fp_fallback')
+    for name in ('head', 'embed', 'proj0', 'fc2_1', 'qkv1_fc1_0'):
+        m = _micro_model(dva, micro)
+        bc = [int(b) for b in gf['bits/' + name]]
+        with torch.no_grad():
+            dva.harness.calibrate_model(m, micro['x_cal'])
+            assert m._fused()
+            out = m(micro['x_ev'], bc, False)[0]                      # CPU tensor + quant state: fine, -1 is not the engine's business
+            flipped = np.array([[b.norm1.mode == 'ln', b.norm2.mode == 'ln'] for b in m.blocks])
+            assert np.array_equal(flipped, gf['norm_modes/' + name]), name
+            s_o = float(m.act_out.quantizer.scale)
+            # torch fake-quant graph vs the reference's: same ops; the canonical exact sums of LN / LIS may move single codes
+            assert np.abs(out.numpy() - gf['logits/' + name]).max() <= 1.01 * s_o, name
+            assert float((out.numpy() == gf['logits/' + name]).mean()) > 0.9, name
+            if flipped.any():
+                assert not m._fused()                                 # a float norm: [8]*10 is no longer the integer pipeline
+                after = m(micro['x_ev'], [8] * 10, False)[0]
+                assert np.abs(after.numpy() - gf['after_q8/' + name]).max() <= 1.01 * s_o, name
+            else:
+                assert m._fused()
