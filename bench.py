@@ -29,13 +29,13 @@ PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA: 2x the ~2.5 PF dense bf16 rate (MI3
 PEAK_HBM_GBS = 8000.0     # HBM3E spec (same guide)
 
 
-def algorithmic_work(kind, arch, B):
+def algorithmic_work(kind, arch, B, bits=8):
     """(ops, bytes) of ONE launch of a kernel kind.  ops = 2*MAC of the dense contraction (SURVEY.md 8d);
-    bytes = compulsory HBM traffic (operands read once + result written once)."""
+    bytes = compulsory HBM traffic (operands read once + result written once); 4-bit weights are stored packed, two per byte."""
     D, H, P = arch['embed_dim'], arch['num_heads'], arch['patch_size']
     T = (arch['img_size'] // P) ** 2 + 1
     Hd, M, hd, K0 = int(D * arch['mlp_ratio']), B * T, D // H, 3 * P * P
-    g = lambda m, k, n, out_b=1, extra=0: (2.0 * m * k * n, m * k + n * k + m * n * out_b + extra)
+    g = lambda m, k, n, out_b=1, extra=0: (2.0 * m * k * n, m * k + n * k * bits // 8 + m * n * out_b + extra)
     return {
         'patchify': (0.0, B * 3 * arch['img_size'] ** 2 * 4 + B * (T - 1) * K0),
         'gemm_embed': g(B * (T - 1), K0, D),
@@ -263,7 +263,7 @@ def main():
     tot = {k: n_sl * sum(v) / 5 for k, v in prof.items()}        # per step: every slice issues the same launches
     dom = max(tot, key=tot.get)
     avg_ms = sum(prof[dom]) / len(prof[dom])
-    ops, byts = algorithmic_work(dom, arch, Bl)
+    ops, byts = algorithmic_work(dom, arch, Bl, args.bits)
     if ops > 0:
         ach = ops / (avg_ms * 1e-3) / 1e12
         roof = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=PEAK_INT8_TOPS, unit='TFLOP/s',
@@ -288,7 +288,7 @@ def main():
         except Exception:
             pass
     breakdown = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
-    model_ops = sum(algorithmic_work(k, arch, Bl)[0] * n_sl * (len(v) // 5) for k, v in prof.items())
+    model_ops = sum(algorithmic_work(k, arch, Bl, args.bits)[0] * n_sl * (len(v) // 5) for k, v in prof.items())
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

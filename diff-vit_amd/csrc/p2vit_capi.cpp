@@ -100,7 +100,7 @@ int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
   p->k_patch_pad = round_up(p->k_patch, GBK_PAD);
   p->n_layers = 4 * d.depth + 2;
   for (int b = 0; b < 2; ++b) {
-    p->lin[b].assign(p->n_layers, p2v_linear{nullptr, nullptr, nullptr, nullptr});
+    p->lin[b].assign(p->n_layers, p2v_linear{nullptr, nullptr, nullptr, nullptr, 0});
     p->lin_set[b].assign(p->n_layers, 0);
   }
   p->blocks.resize(d.depth);
@@ -119,6 +119,7 @@ int p2v_plan_set_linear(p2v_plan* plan, int layer, int bits, const p2v_linear* l
   if (bi < 0) return fail(P2V_E_BITS, "bits %d not in {4, 8}", bits);
   if (layer < 0 || layer >= plan->n_layers) return fail(P2V_E_ARG, "layer %d out of range [0,%d)", layer, plan->n_layers);
   if (!lin->w_codes || !lin->colscale || !lin->bias) return fail(P2V_E_ARG, "p2v_plan_set_linear: null device pointer");
+  if (lin->packed4 && bits != 4) return fail(P2V_E_BITS, "packed4 weights for a %d-bit layer", bits);
   plan->lin[bi][layer] = *lin;
   plan->lin_set[bi][layer] = 1;
   return P2V_OK;
@@ -192,7 +193,7 @@ long long p2v_workspace_view(const p2v_plan* plan, int batch, const char* name) 
 static int run_gemm(int epi, const int8_t* A, int lda, int M, int K, int N, const p2v_linear& lin, const p2v_epilogue& ep, void* out,
                     int ldo, int8_t* out_codes, hipStream_t st) {
   GemmArgs g;
-  g.A = A; g.lda = lda; g.M = M; g.W = lin.w_codes; g.K = K; g.N = N;
+  g.A = A; g.lda = lda; g.M = M; g.W = lin.w_codes; g.K = K; g.N = N; g.w4 = lin.packed4 ? 1 : 0;
   g.colscale = lin.colscale; g.bias = lin.bias; g.ep = ep; g.out = out; g.ldo = ldo; g.out_codes = out_codes; g.tiles_n = 0;
 #ifdef P2V_DIAG
   g.stamps = nullptr;
@@ -204,7 +205,7 @@ static int run_gemm(int epi, const int8_t* A, int lda, int M, int K, int N, cons
 static int run_ln_gemm(int epi, const LnArgs& a, const p2v_linear& lin, const p2v_epilogue& ep, int N, int8_t* out, hipStream_t st) {
   GemmArgs g;
   if (!lin.w_frag) return fail(P2V_E_UNSUPPORTED, "ln_gemm: the layer has no fragment-order weights (p2v_linear.w_frag)");
-  g.A = nullptr; g.lda = a.C; g.M = (int)a.rows; g.W = lin.w_frag; g.K = round_up(a.C, GBK_PAD); g.N = N;
+  g.A = nullptr; g.lda = a.C; g.M = (int)a.rows; g.W = lin.w_frag; g.K = round_up(a.C, GBK_PAD); g.N = N; g.w4 = 0;
   g.colscale = lin.colscale; g.bias = lin.bias; g.ep = ep; g.out = out; g.ldo = N; g.out_codes = nullptr; g.tiles_n = 0;
 #ifdef P2V_DIAG
   g.stamps = nullptr;

@@ -10,8 +10,9 @@
 struct GemmArgs {
   const int8_t* A;      // activations [M][lda] int8
   int lda, M;
-  const int8_t* W;      // weight codes [n_pad][K] int8
+  const int8_t* W;      // weight codes [n_pad][K] int8, or (w4) packed int4 tiles [n_pad/128][K/64][128][32 B]
   int K, N;
+  int w4;               // 1: W is the packed int4 layout (p2v_linear.packed4)
   const float* colscale;
   const float* bias;
   p2v_epilogue ep;

@@ -62,6 +62,23 @@ __device__ __forceinline__ void row16_to_halves(uint4 e, unsigned& g0, unsigned&
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Packed int4 weights (p2v_linear.packed4, include/p2vit.h): two codes per byte.  gfx950 has no int4 MFMA, so a fragment is
+// widened in registers to the int8 operand of v_mfma_i32_32x32x32_i8 -- as (code << 4), i.e. 16 x code, which is exact in int8
+// ([-128, 112]) and costs 3 VALU per dword (shift, and, and) instead of a sign extension per nibble; the accumulator then holds
+// 16 x the true sum, its conversion to fp32 is still exact (a 24-bit integer shifted by 4), and the 1/16 is folded into the
+// power-of-two column scale when the epilogue constants are staged.
+//   8 bytes of a lane = its 16 consecutive k: byte j of dword 0 = code[j] | code[4+j] << 4, of dword 1 = code[8+j] | code[12+j] << 4,
+//   so the even / odd nibble planes come out as the dwords [0..3], [4..7], [8..11], [12..15] of the int8 fragment.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ v4i unpack_w4(unsigned lo, unsigned hi) {
+  const unsigned m = 0xF0F0F0F0u;
+  return (v4i){(int)((lo << 4) & m), (int)(lo & m), (int)((hi << 4) & m), (int)(hi & m)};
+}
+// byte offset of the 8-byte chunk c (k = 16c .. 16c+15) of row `row` inside a packed [128][32 B] tile: chunk index XOR-swizzled by
+// (row>>3)&3 so that a ds_read_b64 of 32 rows x one chunk touches every bank once
+__device__ __forceinline__ int lds_off_w4(int row, int c) { return row * 32 + ((c ^ ((row >> 3) & 3)) << 3); }
+
+// ---------------------------------------------------------------------------------------------------
 // GELU -> PoT requant.  Canonical value: q = clamp(rne(RN32(gelu(y)) / s)), gelu(y) = 0.5*y*erfc(-y/sqrt2)
 // (reference: float nn.GELU then QAct, layers_quant.py:331-333).  Fast path: A&S 7.1.26 erfc (|err| <=
 // 1.5e-7) in fp32; its total error is far below GELU_EPS, so whenever the scaled value is further than
@@ -332,7 +349,7 @@ __device__ __forceinline__ void gemm_stage_epilogue(EpiLds* e, int n0, int tid, 
     // REQUANT: (acc*cs + b) * 2^e == acc*(cs*2^e) + b*2^e with the same single rounding (power-of-two scaling commutes with
     // rounding; the plan checks that 1/s_out is a power of two), so the multiply leaves the per-output chain
     const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : 1.0f;
-    e->colscale[tid] = g.colscale[n] * fold;          // arrays are padded to n_pad
+    e->colscale[tid] = g.colscale[n] * fold * (g.w4 ? 0.0625f : 1.0f);   // arrays are padded to n_pad; packed int4: acc = 16 x sum
     e->bias[tid] = g.bias[n] * fold;
     const bool ok = n < g.N;
     if (EPI == P2V_EPI_RESID) {
@@ -455,10 +472,17 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
 }
 
 // one k-tile of MFMA work for a wave: 2 k-steps x (1 weight frag, 2 activation frags, 2 MFMAs)
+template <bool W4>
 __device__ __forceinline__ void gemm_compute_tile(const int8_t* cx, const int8_t* cw, int wm, int wn, int l31, int h, v16i (&acc)[2]) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    const v4i fw = *reinterpret_cast<const v4i*>(cw + lds_off64(wn * 32 + l31, 2 * ks + h));
+    v4i fw;
+    if (W4) {
+      const uint2 p = *reinterpret_cast<const uint2*>(cw + lds_off_w4(wn * 32 + l31, 2 * ks + h));
+      fw = unpack_w4(p.x, p.y);
+    } else {
+      fw = *reinterpret_cast<const v4i*>(cw + lds_off64(wn * 32 + l31, 2 * ks + h));
+    }
     const v4i f0 = *reinterpret_cast<const v4i*>(cx + lds_off64(wm * 64 + l31, 2 * ks + h));
     const v4i f1 = *reinterpret_cast<const v4i*>(cx + lds_off64(wm * 64 + 32 + l31, 2 * ks + h));
     acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw, f0, acc[0], 0, 0, 0);
@@ -471,7 +495,7 @@ __device__ __forceinline__ void gemm_compute_tile(const int8_t* cx, const int8_t
 // per SIMD and ~2.1 at 4 (tools/ubench/valu_rate.hip), so the kernel is shaped for <= 128 VGPRs -> 2 workgroups
 // (16 waves) per CU.  Global->LDS staging goes through a 3-deep ring of NAMED registers (an indexed array of
 // prefetch registers is placed in scratch by hipcc: measured), one barrier per k-tile.
-template <int EPI>
+template <int EPI, bool W4>
 __global__ __launch_bounds__(512, 4) void k_gemm_i8(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) int8_t lds[2 * (GBM + GBN) * GBK + sizeof(EpiLds)];
   int8_t* sX = lds;                    // [2][GBM][GBK] activation rows
@@ -491,7 +515,8 @@ __global__ __launch_bounds__(512, 4) void k_gemm_i8(GemmArgs g) {
   int mr0 = m0 + lrow;
   mr0 = mr0 < g.M ? mr0 : g.M - 1;
   const int8_t* gx0 = g.A + (long long)mr0 * g.lda + lchunk * 16;
-  const int8_t* gw0 = g.W + (long long)(n0 + lrow) * g.K + lchunk * 16;
+  // packed int4: the W tile of k-tile T is the contiguous 4 KB block (tn * nk + T), an LDS image: threads 0..255 copy 16 bytes each
+  const int8_t* gw0 = W4 ? g.W + (long long)tn * (g.K / GBK) * 4096 + (tid & 255) * 16 : g.W + (long long)(n0 + lrow) * g.K + lchunk * 16;
   const int o0 = lds_off64(lrow, lchunk);
 
   v16i acc[2];
@@ -505,17 +530,18 @@ __global__ __launch_bounds__(512, 4) void k_gemm_i8(GemmArgs g) {
 #define G_LOAD(P, T)                                                        \
   do {                                                                      \
     P##x0 = *reinterpret_cast<const uint4*>(gx0 + (T) * GBK);               \
-    P##w0 = *reinterpret_cast<const uint4*>(gw0 + (T) * GBK);               \
+    P##w0 = *reinterpret_cast<const uint4*>(gw0 + (T) * (W4 ? 4096 : GBK));  \
   } while (0)
 #define G_STEP(P, T)                                                        \
   do {                                                                      \
     int8_t* bx_ = sX + ((T) & 1) * GBM * GBK;                               \
     int8_t* bw_ = sW + ((T) & 1) * GBN * GBK;                               \
     *reinterpret_cast<uint4*>(bx_ + o0) = P##x0;                            \
-    *reinterpret_cast<uint4*>(bw_ + o0) = P##w0;                            \
+    if (!W4) *reinterpret_cast<uint4*>(bw_ + o0) = P##w0;                   \
+    else if (tid < 256) *reinterpret_cast<uint4*>(bw_ + tid * 16) = P##w0;  \
     __syncthreads();                                                        \
     if ((T) + 3 < nk) G_LOAD(P, (T) + 3);                                   \
-    gemm_compute_tile(bx_, bw_, wm, wn, l31, h, acc);                       \
+    gemm_compute_tile<W4>(bx_, bw_, wm, wn, l31, h, acc);                   \
   } while (0)
   G_LOAD(a, 0);
   if (nk > 1) G_LOAD(b, 1);
@@ -690,7 +716,32 @@ __global__ __launch_bounds__(256, 3) void k_gemm_i8_w4(GemmArgs g) {
 //   DMA is pending (it cannot prove they do not alias), which would serialise the pipeline; __syncthreads() likewise drains vmcnt,
 //   hence the raw s_barrier.
 // ---------------------------------------------------------------------------------------------------
-#define DMA_STAGE_BYTES (2 * GBM * GBK)     // 16 KB: X tile + W tile
+#define DMA_STAGE_BYTES (2 * GBM * GBK)     // 16 KB: X tile + W tile (a packed int4 W tile fills half of its 8 KB)
+// packed int4 weights: the W fragments are 8-byte reads of the [128][32 B] tile image, widened in registers (unpack_w4)
+template <int OFF>
+__device__ __forceinline__ void gemm_compute_tile_dma_w4(unsigned aX0, unsigned aX1, unsigned aW0, unsigned aW1, v16i (&acc)[2][2]) {
+  v4i x0a, x1a, x0b, x1b;
+  v2u p0a, p1a, p0b, p1b;
+  const unsigned bX0 = aX0 ^ 32u, bX1 = aX1 ^ 32u, bW0 = aW0 ^ 16u, bW1 = aW1 ^ 16u;     // k-step 1: chunk ^ 2
+  asm volatile(
+      "ds_read_b64 %0, %8 offset:%16\n\tds_read_b64 %1, %9 offset:%16\n\tds_read_b128 %2, %10 offset:%16\n\tds_read_b128 %3, %11 offset:%16\n\t"
+      "ds_read_b64 %4, %12 offset:%16\n\tds_read_b64 %5, %13 offset:%16\n\tds_read_b128 %6, %14 offset:%16\n\tds_read_b128 %7, %15 offset:%16\n\t"
+      "s_waitcnt lgkmcnt(4)"
+      : "=&v"(p0a), "=&v"(p1a), "=&v"(x0a), "=&v"(x1a), "=&v"(p0b), "=&v"(p1b), "=&v"(x0b), "=&v"(x1b)
+      : "v"(aW0), "v"(aW1), "v"(aX0), "v"(aX1), "v"(bW0), "v"(bW1), "v"(bX0), "v"(bX1), "i"(OFF)
+      : "memory");
+  const v4i w0a = unpack_w4(p0a[0], p0a[1]), w1a = unpack_w4(p1a[0], p1a[1]);
+  acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0a, x0a, acc[0][0], 0, 0, 0);
+  acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0a, x1a, acc[0][1], 0, 0, 0);
+  acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1a, x0a, acc[1][0], 0, 0, 0);
+  acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1a, x1a, acc[1][1], 0, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p0b), "+v"(p1b), "+v"(x0b), "+v"(x1b));
+  const v4i w0b = unpack_w4(p0b[0], p0b[1]), w1b = unpack_w4(p1b[0], p1b[1]);
+  acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0b, x0b, acc[0][0], 0, 0, 0);
+  acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0b, x1b, acc[0][1], 0, 0, 0);
+  acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1b, x0b, acc[1][0], 0, 0, 0);
+  acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1b, x1b, acc[1][1], 0, 0, 0);
+}
 template <int OFF>
 __device__ __forceinline__ void gemm_compute_tile_dma(unsigned aX0, unsigned aX1, unsigned aW0, unsigned aW1, v16i (&acc)[2][2]) {
   // a*: LDS byte addresses of this lane's fragment rows at k-step 0; k-step 1 is the same address with bit 5 flipped (chunk ^ 2)
@@ -714,7 +765,7 @@ __device__ __forceinline__ void gemm_compute_tile_dma(unsigned aX0, unsigned aX1
   acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1b, x1b, acc[1][1], 0, 0, 0);
 }
 
-template <int EPI, int NST>
+template <int EPI, int NST, bool W4>
 __global__ __launch_bounds__(256, NST == 2 ? 4 : 3) void k_gemm_dma(GemmArgs g) {
   constexpr int EPI_BYTES = (EPI == P2V_EPI_RESID) ? (int)sizeof(EpiLds) : 2 * GBN * (int)sizeof(float);   // colscale + bias only
   __shared__ __attribute__((aligned(1024))) int8_t lds[NST * DMA_STAGE_BYTES + EPI_BYTES];
@@ -739,6 +790,8 @@ __global__ __launch_bounds__(256, NST == 2 ? 4 : 3) void k_gemm_dma(GemmArgs g) 
   const int8_t* gxb = g.A + (long long)mrb * g.lda + ((pc ^ ((rb >> 2) & 3)) << 4);
   const int8_t* gwa = g.W + (long long)(n0 + ra) * g.K + ((pc ^ ((ra >> 2) & 3)) << 4);
   const int8_t* gwb = g.W + (long long)(n0 + rb) * g.K + ((pc ^ ((rb >> 2) & 3)) << 4);
+  // packed int4: the W tile of k-tile kt is the contiguous 4 KB LDS image (tn * nk + kt): one coalesced 1 KB piece per wave
+  const int8_t* gw4 = g.W + (long long)tn * (g.K / GBK) * 4096 + wave * 1024 + lane * 16;
   auto dma = [&](int stage, int kt) {
     int8_t* dst = lds + stage * DMA_STAGE_BYTES + wave * (32 * GBK);
     const int ko = kt * GBK;
@@ -746,8 +799,12 @@ __global__ __launch_bounds__(256, NST == 2 ? 4 : 3) void k_gemm_dma(GemmArgs g) 
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
     P2V_DMA16_(gxa + ko, dst);
     P2V_DMA16_(gxb + ko, dst + 16 * GBK);
-    P2V_DMA16_(gwa + ko, dst + GBM * GBK);
-    P2V_DMA16_(gwb + ko, dst + GBM * GBK + 16 * GBK);
+    if (W4) {
+      P2V_DMA16_(gw4 + (long long)kt * 4096, lds + stage * DMA_STAGE_BYTES + GBM * GBK + wave * 1024);
+    } else {
+      P2V_DMA16_(gwa + ko, dst + GBM * GBK);
+      P2V_DMA16_(gwb + ko, dst + GBM * GBK + 16 * GBK);
+    }
 #undef P2V_DMA16_
   };
   const int nk = g.K / GBK;
@@ -782,23 +839,27 @@ __global__ __launch_bounds__(256, NST == 2 ? 4 : 3) void k_gemm_dma(GemmArgs g) 
 
   const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int8_t*)lds;
   const unsigned aX0 = lbase + lds_off64(wm * 64 + l31, h), aX1 = lbase + lds_off64(wm * 64 + 32 + l31, h);
-  const unsigned aW0 = lbase + GBM * GBK + lds_off64(wn * 64 + l31, h), aW1 = lbase + GBM * GBK + lds_off64(wn * 64 + 32 + l31, h);
+  const unsigned aW0 = lbase + GBM * GBK + (W4 ? lds_off_w4(wn * 64 + l31, h) : lds_off64(wn * 64 + l31, h));
+  const unsigned aW1 = lbase + GBM * GBK + (W4 ? lds_off_w4(wn * 64 + 32 + l31, h) : lds_off64(wn * 64 + 32 + l31, h));
+  constexpr int PCS = W4 ? 3 : 4;        // LDS-DMA requests of one wave per k-tile
 
   // one k-tile: own pieces landed (younger requests stay in flight) -> barrier -> refill the freed stage -> MFMAs
 #define P2V_KTILE(S, KT)                                                                                             \
   do {                                                                                                               \
     if (NST == 3) {                                                                                                  \
       /* in flight behind tile KT: tile KT+1 (4 requests of this wave) */                                            \
-      if ((KT) + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                            \
+      if ((KT) + 1 < nk) { if (PCS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } \
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
       asm volatile("s_barrier" ::: "memory");    /* tile KT landed for everyone; everyone is done reading tile KT-1 */ \
       if ((KT) + 2 < nk) dma(((S) + 2) % 3, (KT) + 2);                                                               \
-      gemm_compute_tile_dma<(S) * DMA_STAGE_BYTES>(aX0, aX1, aW0, aW1, acc);                                         \
+      if (W4) gemm_compute_tile_dma_w4<(S) * DMA_STAGE_BYTES>(aX0, aX1, aW0, aW1, acc);                              \
+      else gemm_compute_tile_dma<(S) * DMA_STAGE_BYTES>(aX0, aX1, aW0, aW1, acc);                                    \
     } else {                                                                                                         \
-      if ((KT) + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                            \
+      if ((KT) + 1 < nk) { if (PCS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } \
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
       asm volatile("s_barrier" ::: "memory");                                                                        \
-      gemm_compute_tile_dma<(S) * DMA_STAGE_BYTES>(aX0, aX1, aW0, aW1, acc);                                         \
+      if (W4) gemm_compute_tile_dma_w4<(S) * DMA_STAGE_BYTES>(aX0, aX1, aW0, aW1, acc);                              \
+      else gemm_compute_tile_dma<(S) * DMA_STAGE_BYTES>(aX0, aX1, aW0, aW1, acc);                                    \
       if ((KT) + 2 < nk) {                                                                                           \
         asm volatile("s_barrier" ::: "memory");                                                                      \
         dma((S), (KT) + 2);                                                                                          \
@@ -1723,9 +1784,11 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
       default: return -1;                                                                                                 \
     }
 #define P2V_K_W4(E) (k_gemm_i8_w4<E>)
-#define P2V_K_DMA2(E) (k_gemm_dma<E, 2>)
-#define P2V_K_DMA3(E) (k_gemm_dma<E, 3>)
-    if (g_gemm_stages == 2) { P2V_LAUNCH_TILED(P2V_K_DMA2) }
+#define P2V_K_DMA2(E) (k_gemm_dma<E, 2, false>)
+#define P2V_K_DMA3(E) (k_gemm_dma<E, 3, false>)
+#define P2V_K_DMA3P(E) (k_gemm_dma<E, 3, true>)
+    if (g.w4) { P2V_LAUNCH_TILED(P2V_K_DMA3P) }          // packed int4 weights: the LDS-DMA kernel only
+    else if (g_gemm_stages == 2) { P2V_LAUNCH_TILED(P2V_K_DMA2) }
     else if (g_gemm_stages == 3) { P2V_LAUNCH_TILED(P2V_K_DMA3) }
     else { P2V_LAUNCH_TILED(P2V_K_W4) }
 #undef P2V_LAUNCH_TILED
@@ -1734,8 +1797,13 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   }
   // EMBED / HEAD: one launch each per forward; 8-wave shape (64x32 wave tiles, <= 128 VGPRs)
   dim3 grid(g.tiles_n * tiles_m), block(512);
-  if (epi == P2V_EPI_EMBED) hipLaunchKernelGGL(k_gemm_i8<P2V_EPI_EMBED>, grid, block, 0, st, g);
-  else hipLaunchKernelGGL(k_gemm_i8<P2V_EPI_HEAD>, grid, block, 0, st, g);
+  if (epi == P2V_EPI_EMBED) {
+    if (g.w4) hipLaunchKernelGGL((k_gemm_i8<P2V_EPI_EMBED, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((k_gemm_i8<P2V_EPI_EMBED, false>), grid, block, 0, st, g);
+  } else {
+    if (g.w4) hipLaunchKernelGGL((k_gemm_i8<P2V_EPI_HEAD, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((k_gemm_i8<P2V_EPI_HEAD, false>), grid, block, 0, st, g);
+  }
   CHECK_LAUNCH();
   return 0;
 }

@@ -26,7 +26,7 @@ class ModelDesc(C.Structure):
 
 
 class Linear(C.Structure):
-    _fields_ = [('w_codes', _p), ('colscale', _p), ('bias', _p), ('w_frag', _p)]
+    _fields_ = [('w_codes', _p), ('colscale', _p), ('bias', _p), ('w_frag', _p), ('packed4', _i)]
 
 
 class Ln(C.Structure):
@@ -184,6 +184,22 @@ def fragment_order(wp):
     n_pad, k_pad = wp.shape
     assert n_pad % 128 == 0 and k_pad % 64 == 0
     return wp.reshape(n_pad // 128, 4, 32, k_pad // 32, 2, 16).permute(0, 1, 3, 4, 2, 5).contiguous()
+
+
+def pack_int4_tiles(wp):
+    """int8 codes in [-8, 7], [n_pad (x128)][k_pad (x64)] -> the packed layout of ``p2v_linear.packed4`` (include/p2vit.h): uint8
+    [n_pad/128][k_pad/64][128][32]: two codes per byte, the LDS image of every weight tile (chunk swizzle included)."""
+    import torch
+    n_pad, k_pad = wp.shape
+    assert n_pad % 128 == 0 and k_pad % 64 == 0 and int(wp.min()) >= -8 and int(wp.max()) <= 7
+    w = (wp.to(torch.int16) & 15).to(torch.uint8).reshape(n_pad // 128, 128, k_pad // 64, 4, 16)       # [tile, row, ktile, chunk, 16 codes]
+    lo = w[..., [0, 1, 2, 3, 8, 9, 10, 11]]
+    hi = w[..., [4, 5, 6, 7, 12, 13, 14, 15]]
+    b = lo | (hi << 4)                                                                           # [tile, row, ktile, chunk, 8 bytes]
+    rows = torch.arange(128)
+    src = torch.arange(4).reshape(1, 4) ^ ((rows >> 3) & 3).reshape(128, 1)                      # position c' holds chunk c' ^ f(row)
+    b = torch.gather(b, 3, src.reshape(1, 128, 1, 4, 1).expand(b.shape[0], 128, b.shape[2], 4, 8))
+    return b.permute(0, 2, 1, 3, 4).reshape(n_pad // 128, k_pad // 64, 128, 32).contiguous()
 
 
 def ptr(t):

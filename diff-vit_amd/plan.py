@@ -108,7 +108,9 @@ class FrozenPlan:
             bp = torch.zeros(n_pad)
             if bias is not None:
                 bp[:N] = bias
-            lin = E.Linear(E.ptr(self._dev(wp, torch.int8)), E.ptr(self._dev(cs_col)), E.ptr(self._dev(bp)))
+            # 4-bit weights travel packed, two codes per byte (half the HBM bytes of BASELINE config 5), as LDS tile images
+            wdev = self._dev(E.pack_int4_tiles(wp), torch.uint8) if bits == 4 else self._dev(wp, torch.int8)
+            lin = E.Linear(E.ptr(wdev), E.ptr(self._dev(cs_col)), E.ptr(self._dev(bp)), None, 1 if bits == 4 else 0)
             E.check(L.p2v_plan_set_linear(self._handle, layer, bits, C.byref(lin)))
 
     def _ln(self, in_scale, gamma, beta, out_scale, post_mul):
@@ -217,8 +219,9 @@ class FrozenPlan:
             bp = torch.zeros(n_pad)
             bp[:N] = bias
             # qkv / fc1 follow a LayerNorm: a second copy in MFMA-fragment order feeds the fused LayerNorm+GEMM kernel
-            lin = E.Linear(E.ptr(self._dev(wp, torch.int8)), E.ptr(self._dev(cs_col)), E.ptr(self._dev(bp)),
-                           E.ptr(self._dev(E.fragment_order(wp), torch.int8)))
+            wdev = self._dev(E.pack_int4_tiles(wp), torch.uint8) if bits == 4 else self._dev(wp, torch.int8)
+            lin = E.Linear(E.ptr(wdev), E.ptr(self._dev(cs_col)), E.ptr(self._dev(bp)),
+                           E.ptr(self._dev(E.fragment_order(wp), torch.int8)) if self.D <= 384 else None, 1 if bits == 4 else 0)
             E.check(L.p2v_plan_set_linear(self._handle, layer, bits, C.byref(lin)))
 
     # ---------------------------------------------------------------------------------------------

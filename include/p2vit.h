@@ -61,8 +61,13 @@ typedef struct p2v_model_desc {
 } p2v_model_desc;
 
 /* One fake-quantised weight matrix for one bit width (QLinear/QConv2d.forward, layers.py:82-88,173-178;
- * UniformQuantizer.quant, uniform.py:50-88).  Codes are stored one per byte ([-8,7] for 4-bit), row
+ * UniformQuantizer.quant, uniform.py:50-88).  packed4 == 0: codes one per byte ([-8,7] for 4-bit), row
  * major [n_pad][k_pad], n_pad = round_up(N,128), k_pad = round_up(K,64), zero padded.
+ * packed4 == 1 (4-bit codes only): two codes per byte, stored as the LDS images of the GEMM's weight tiles --
+ *   [n_pad/128 column tiles][k_pad/64 k-tiles][128 rows][32 bytes]; the 32 bytes of row r hold its 64 k-values as four 8-byte chunks
+ *   c (k = 16c .. 16c+15) at chunk position c ^ ((r >> 3) & 3) (bank swizzle); inside a chunk byte j of dword 0 is
+ *   code[j] | code[4+j] << 4 and byte j of dword 1 is code[8+j] | code[12+j] << 4 (low nibble first, two's complement nibbles).
+ *   Half the bytes, one contiguous 4 KB block per tile; gfx950 has no int4 MFMA, the kernels widen the nibbles to int8 in registers.
  * colscale[n] = s_x * s_w[n]  (activation scale times per-tensor (int8) or per-out-channel (int4) weight
  * scale; both powers of two, so the product is exact).  bias is the un-quantised fp32 bias. */
 typedef struct p2v_linear {
@@ -72,7 +77,8 @@ typedef struct p2v_linear {
   const int8_t* w_frag;  /* dev, optional (NULL): the same codes in MFMA-fragment order for p2v_ln_gemm_i8 --
                           * [n_pad/128 column tiles][4 waves][k_pad/32 k-steps][64 lanes][16 bytes], lane = 32*h + r holding
                           * W[128*tile + 32*wave + r][32*kstep + 16*h .. +16): the A operand of v_mfma_i32_32x32x32_i8 as one
-                          * coalesced 1 KB load per wave */
+                          * coalesced 1 KB load per wave (always one code per byte) */
+  int32_t packed4;       /* 1: w_codes is the packed int4 tile layout described above */
 } p2v_linear;
 
 /* QIntLayerNorm.forward mode 'int' (layers.py:255-289) fused with the division by the SmoothQuant

@@ -81,3 +81,29 @@ def test_run_ops_and_swin_entry_validation_without_gpu():
         E.check(L.p2v_patch_merge_gather(one, 1, 7, 7, 64, one, None))
     with pytest.raises(NotImplementedError):
         E.check(L.p2v_avgpool_quant(one, 1, 49, 6, 1.0, 1.0, one, None))
+
+
+def test_int4_tile_packing_layout():
+    """engine.pack_int4_tiles against a literal reading of the layout in include/p2vit.h (p2v_linear.packed4)."""
+    import numpy as np
+    import torch
+    import diff_vit_amd as dva
+    g = torch.Generator().manual_seed(3)
+    w = torch.randint(-8, 8, (256, 128), generator=g, dtype=torch.int8)
+    p = dva.engine.pack_int4_tiles(w).numpy()
+    assert p.shape == (2, 2, 128, 32) and p.dtype == np.uint8
+    wn = w.numpy().astype(np.int64)
+    for (t, kt, r, c, j) in ((0, 0, 0, 0, 0), (1, 1, 127, 3, 7), (0, 1, 9, 2, 5), (1, 0, 77, 1, 3), (0, 0, 24, 0, 6)):
+        chunk = p[t, kt, r, (c ^ ((r >> 3) & 3)) * 8:(c ^ ((r >> 3) & 3)) * 8 + 8]
+        k0 = kt * 64 + c * 16
+        lo_k, hi_k = (k0 + j, k0 + 4 + j) if j < 4 else (k0 + 8 + (j - 4), k0 + 12 + (j - 4))
+        row = t * 128 + r
+        assert chunk[j] == ((wn[row, lo_k] & 15) | ((wn[row, hi_k] & 15) << 4)), (t, kt, r, c, j)
+    # the kernel's widening: (byte << 4) & 0xF0 / byte & 0xF0 as int8 = 16 x code
+    b = p[0, 0, 5, :8].astype(np.uint8)
+    even = ((b.astype(np.uint16) << 4) & 0xF0).astype(np.uint8).view(np.int8)
+    odd = (b & 0xF0).view(np.int8)
+    c0 = 0 ^ ((5 >> 3) & 3)
+    assert c0 == 0
+    assert np.array_equal(even[:4], 16 * wn[5, 0:4]) and np.array_equal(odd[:4], 16 * wn[5, 4:8])
+    assert np.array_equal(even[4:], 16 * wn[5, 8:12]) and np.array_equal(odd[4:], 16 * wn[5, 12:16])

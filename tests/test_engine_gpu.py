@@ -212,6 +212,56 @@ def test_gemm_requant_and_gelu(dva, oracle, M, K, N):
         assert ref.abs().max() == 128 or ref.max() == 127          # clamps exercised
 
 
+@pytest.mark.parametrize('M,K,N', [(300, 64, 192), (394, 384, 1152), (130, 1536, 384), (77, 768, 1000)])
+def test_gemm_packed_int4_weights(dva, oracle, M, K, N):
+    """p2v_linear.packed4: two 4-bit codes per byte in the tile-image layout, widened to int8 in registers.  Every epilogue on packed
+    weights equals the same call on one-code-per-byte weights (bit for bit) and the oracle's qgemm."""
+    E, S = dva.engine, dva.synth
+    x = _rand_codes(S, 17, 'px', (M, K))
+    w = torch.clamp(torch.round(S.normal(17, 'pw', (N, K), 3.5)), -8, 7)
+    assert w.min() == -8 and w.max() == 7
+    bias = S.normal(17, 'pb', (N,), 0.4)
+    s_x, s_w = 2.0 ** -5, 2.0 ** -torch.floor(S.uniform(17, 'ps', (N,), 2, 5.99))       # per-out-channel scales (int4 style)
+    n_pad = (N + 127) // 128 * 128
+    wp = torch.zeros(n_pad, K, dtype=torch.int8); wp[:N] = w.to(torch.int8)
+    cs = torch.zeros(n_pad); cs[:N] = s_x * s_w
+    bp = torch.zeros(n_pad); bp[:N] = bias
+    d = [t.cuda() for t in (x.to(torch.int8), wp, E.pack_int4_tiles(wp), cs, bp)]
+    assert d[2].numel() * 2 == d[1].numel()                       # half the bytes
+    lin8 = E.Linear(E.ptr(d[1]), E.ptr(d[3]), E.ptr(d[4]))
+    lin4 = E.Linear(E.ptr(d[2]), E.ptr(d[3]), E.ptr(d[4]), None, 1)
+    y = oracle.qgemm(x, torch.tensor(s_x), w, s_w, bias)
+    res = _rand_codes(S, 17, 'pr', (M, N), 50.0).to(torch.int8).cuda()
+    ptf = lambda nm, base: (base * 2.0 ** torch.floor(S.uniform(17, nm, (N,), 0, 3.99))).cuda()
+    sm, sr, sn = ptf('m', 0.0131), ptf('r', 0.0173), ptf('n', 0.0209)
+    for kind, s_out in ((E.EPI_REQUANT, 2.0 ** -3), (E.EPI_GELU, 2.0 ** -5), (E.EPI_RESID, None), (E.EPI_HEAD, 2.0 ** -2)):
+        if kind == E.EPI_RESID and N % 16:
+            continue
+        outs = []
+        for lin in (lin8, lin4):
+            epi = E.Epilogue()
+            if s_out:
+                epi.inv_s_out, epi.s_out = 1.0 / s_out, s_out
+            if kind == E.EPI_GELU:
+                epi.gelu = E.gelu_table(1.0 / s_out, 'cuda')
+            if kind == E.EPI_RESID:
+                epi.s_mid, epi.s_res, epi.s_next, epi.residual = E.ptr(sm), E.ptr(sr), E.ptr(sn), E.ptr(res)
+            out = torch.zeros(M, N, dtype=torch.float32 if kind == E.EPI_HEAD else torch.int8, device='cuda')
+            if kind != E.EPI_HEAD and N % 16:
+                continue
+            E.check(E.lib().p2v_gemm_i8(kind, E.ptr(d[0]), K, M, K, N, C.byref(lin), C.byref(epi), E.ptr(out), N, None, E.stream_ptr()))
+            outs.append(out.cpu().float())
+        if len(outs) < 2:
+            continue
+        assert torch.equal(outs[0], outs[1]), (kind, int((outs[0] != outs[1]).sum()))
+        if kind == E.EPI_REQUANT:
+            assert torch.equal(outs[1], torch.clamp(torch.round(y / s_out), -128, 127))
+        if kind == E.EPI_GELU:
+            assert torch.equal(outs[1], torch.clamp(torch.round(oracle.gelu_rn(y) / s_out), -128, 127))
+        if kind == E.EPI_HEAD:
+            assert torch.equal(outs[1], torch.clamp(torch.round(y / s_out), -128, 127) * s_out)
+
+
 def test_gemm_residual_epilogue(dva, oracle):
     E, S = dva.engine, dva.synth
     M, K, N = 333, 256, 128
