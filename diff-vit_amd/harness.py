@@ -42,6 +42,10 @@ def build_parser():
     p.add_argument('--print-freq', default=100, type=int, help='print frequency')
     p.add_argument('--seed', default=0, type=int, help='seed')
     p.add_argument('--synthetic', default=True, action='store_true', help='synthetic ImageNet-shaped data and random-init weights')
+    p.add_argument('--real-data', default=False, action='store_true',
+                   help='evaluate on the ImageFolder tree under --data (val/, and train/ for --mode 0 calibration) through the PIL port of '
+                        'build_transform (data.py; its equality with torchvision is unpinned)')
+    p.add_argument('--checkpoint', default='', help='local .pth / .npz checkpoint (checkpoint.load_checkpoint); default: seeded synthetic weights')
     p.add_argument('--n-val', default=500, type=int, help='number of synthetic validation images')
     p.add_argument('--bits', default=8, type=int, choices=[4, 8], help='uniform bit_config for the validation run')
     p.add_argument('--calib-on', default='host', choices=['host', 'model'], help="where the calibration pass runs: 'host' reproduces the reference's exponents exactly")
@@ -207,17 +211,31 @@ def main(argv=None):
         model.load_state_dict(synth.swin_state_dict(model.state_dict(), args.seed))
     else:
         model.load_state_dict(synth.vit_state_dict(arch, args.seed), strict=False)
+    if args.checkpoint:
+        from .checkpoint import load_checkpoint
+        load_checkpoint(model, args.checkpoint)
     model = model.to(device).eval()
-    # labels: the float model's own top-1 ("agreement with fp32"), the metric BASELINE.json names besides images/sec
-    loader = SyntheticLoader(args.n_val, args.val_batchsize, arch['img_size'], arch['num_classes'], args.seed, device)
-    with torch.no_grad():
-        tgt = torch.cat([_forward(model, d)[0].argmax(1).cpu() for d, _ in loader])
-    loader = SyntheticLoader(args.n_val, args.val_batchsize, arch['img_size'], arch['num_classes'], args.seed, device, tgt)
+    train_loader = None
+    if args.real_data:
+        # test_quant.py:118-144: ImageFolder val / train trees with the model family's mean / std / crop
+        from .data import build_loaders
+        loader, train_loader = build_loaders(args.data, args.model, args.val_batchsize, args.calib_batchsize, 0)
+    else:
+        # labels: the float model's own top-1 ("agreement with fp32"), the metric BASELINE.json names besides images/sec
+        loader = SyntheticLoader(args.n_val, args.val_batchsize, arch['img_size'], arch['num_classes'], args.seed, device)
+        with torch.no_grad():
+            tgt = torch.cat([_forward(model, d)[0].argmax(1).cpu() for d, _ in loader])
+        loader = SyntheticLoader(args.n_val, args.val_batchsize, arch['img_size'], arch['num_classes'], args.seed, device, tgt)
     criterion = nn.CrossEntropyLoss().to(device)
     bit_config = None
     if args.quant:
-        print('Calibrating with Gaussian noise...')
-        _, FLOPs, global_distance = calibrate_model(model, synth.images(args.seed + 1, args.calib_batchsize, arch['img_size']).to(device), where=args.calib_on)
+        if args.mode == 0 and train_loader is not None:
+            print('Calibrating with real data...')                       # test_quant.py:214-233, mode 0: the first training batch
+            calib_data = next(iter(train_loader))[0].to(device)
+        else:
+            print('Calibrating with Gaussian noise...')
+            calib_data = synth.images(args.seed + 1, args.calib_batchsize, arch['img_size']).to(device)
+        _, FLOPs, global_distance = calibrate_model(model, calib_data, where=args.calib_on)
         if args.mixed and not _is_swin(model):
             # test_quant.py:253-408 on the fast path: every candidate bit_config is one validate() over the HIP engine (the frozen
             # plan holds both weight widths per layer, so switching configurations costs nothing)
