@@ -92,6 +92,12 @@ int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
   const int hd = d.embed_dim / d.num_heads;
   if (hd != 32 && hd != 64) return fail(P2V_E_UNSUPPORTED, "head_dim %d (32 and 64 are instantiated)", hd);
   if (d.embed_dim % 64 || d.mlp_hidden % 64) return fail(P2V_E_UNSUPPORTED, "embed_dim and mlp_hidden must be multiples of 64");
+  {   // the attention kernel is instantiated for ceil(tokens / 32) in {1, 2, 7}: refuse other geometries here, before any upload
+    const int tokens = (d.img_size / d.patch_size) * (d.img_size / d.patch_size) + 1, nkb = (tokens + 31) / 32;
+    if (nkb != 1 && nkb != 2 && nkb != 7)
+      return fail(P2V_E_UNSUPPORTED, "%d tokens per image: the attention kernel covers <= 64 and 193..224 tokens (224^2 / 16)", tokens);
+  }
+  if (d.embed_dim > 2048) return fail(P2V_E_UNSUPPORTED, "embed_dim %d: the LayerNorm kernel covers up to 2048 channels", d.embed_dim);
   p2v_plan* p = new p2v_plan();
   p->d = d;
   p->patches = (d.img_size / d.patch_size) * (d.img_size / d.patch_size);
@@ -411,6 +417,9 @@ int p2v_lis_attention(const int8_t* qkv, int batch, int tokens, int heads, int h
   if (!qkv || !at || !out) return fail(P2V_E_ARG, "p2v_lis_attention: null argument");
   if (batch <= 0 || tokens <= 0 || heads <= 0) return fail(P2V_E_SHAPE, "bad attention shape");
   if (at->x0_int >= 0) return fail(P2V_E_ARG, "x0_int must be negative");
+  // exp_int = z * 2^(32-q) with z = r (r + b) + c: the kernels keep z exactly in fp32 and the table in int64
+  if (at->c_int <= 0 || at->c_int >= (1 << 24) || at->b_int < 0 || at->b_int >= (1 << 23) || at->x0_int < -(1 << 12))
+    return fail(P2V_E_UNSUPPORTED, "log-int-softmax constants out of range (x0 %d, b %d, c %d): qact_attn1 scale below 2^-11?", at->x0_int, at->b_int, at->c_int);
   AttnArgs a{qkv, batch, tokens, heads, *at, out, probs_k};
   return launch_rc(p2v_launch_attention(a, head_dim, (hipStream_t)stream), "lis_attention");
 }
@@ -437,6 +446,8 @@ int p2v_window_attention(const int8_t* qkv, int batch, int tokens_per_image, int
   if (wa->ws < 1 || wa->ws > 8 || wa->n_windows < 1 || wa->ws * wa->ws * wa->n_windows > tokens_per_image)
     return fail(P2V_E_SHAPE, "window attention: window size must be 1..8 and windows must fit the token count");
   if (wa->x0_int >= 0) return fail(P2V_E_ARG, "x0_int must be negative");
+  if (wa->c_int <= 0 || wa->c_int >= (1 << 24) || wa->b_int < 0 || wa->b_int >= (1 << 23) || wa->x0_int < -(1 << 12))
+    return fail(P2V_E_UNSUPPORTED, "log-int-softmax constants out of range (x0 %d, b %d, c %d)", wa->x0_int, wa->b_int, wa->c_int);
   const float pots[5] = {wa->s_q1, wa->s_attn, wa->s_table, wa->s_q2, wa->s_q3};
   for (float s : pots) {
     int ex;

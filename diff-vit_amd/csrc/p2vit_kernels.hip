@@ -83,7 +83,8 @@ __device__ __forceinline__ int lds_off_w4(int row, int c) { return row * 32 + ((
 // (reference: float nn.GELU then QAct, layers_quant.py:331-333).  Fast path: A&S 7.1.26 erfc (|err| <=
 // 1.5e-7) in fp32; its total error is far below GELU_EPS, so whenever the scaled value is further than
 // GELU_EPS/s from a rounding boundary the code is already decided.  Otherwise (about 1e-4 of the
-// elements) the lane takes the fp64 path.  tests/test_gelu_gpu.py sweeps the fp32 line to check the bound.
+// elements) the lane takes the fp64 path.  tests/test_engine_gpu.py::test_gelu_fast_path_bound_and_exactness sweeps the fp32 line
+// to check the bound.  (Frozen plans use the exact threshold table below instead; this path serves scales without a table.)
 // ---------------------------------------------------------------------------------------------------
 #define GELU_EPS 1.2e-6f   // measured max |gelu_fast - RN32(gelu)| over all fp32 in +-[2^-20,32): 4.8e-7 (tools/gelu_stats.py)
 // approximation only (its error is bounded by the exhaustive sweep in tests): fused multiply-adds are fine here

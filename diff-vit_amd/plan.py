@@ -119,6 +119,9 @@ class FrozenPlan:
         D = gamma.numel()
         s1 = in_scale.min()
         mask = torch.round(in_scale / s1).expand(D) if in_scale.numel() == 1 else torch.round(in_scale / s1)
+        # the kernel keeps sum(x_q^2) exactly in 32 unsigned bits: C * (128 * mask)^2 < 2^32 (PTF masks are 1, 2, 4 or 8: ptf.py:96-134)
+        if float(mask.min()) < 1 or D * (128.0 * float(mask.max())) ** 2 >= 2.0 ** 32:
+            raise NotImplementedError('LayerNorm input scale ratios up to %g over %d channels exceed the exact 32-bit statistics' % (float(mask.max()), D))
         out_scale = _need_pot('LN out scale', out_scale.reshape(-1).expand(D).contiguous())
         post_mul = _need_pot('LN post multiplier', post_mul.reshape(-1).expand(D).contiguous())
         return E.Ln(float(s1), E.ptr(self._dev(mask)), E.ptr(self._dev(gamma)), E.ptr(self._dev(beta)),

@@ -98,6 +98,9 @@ class SwinPlan:
         if s_in_vec.numel() == 1:
             s_in_vec = s_in_vec.expand(C_)
         s1 = s_in_vec.min()
+        mask_max = float(torch.round(s_in_vec / s1).max())
+        if C_ * (128.0 * mask_max) ** 2 >= 2.0 ** 32:      # the kernel keeps sum(x_q^2) exactly in 32 unsigned bits
+            raise NotImplementedError('LayerNorm input scale ratios up to %g over %d channels exceed the exact 32-bit statistics' % (mask_max, C_))
         t = [self._dev(torch.round(s_in_vec / s1)), self._dev(self.W[prefix + '.weight']), self._dev(self.W[prefix + '.bias']),
              self._dev(torch.full((C_,), 1.0 / float(s_out))), self._dev(torch.ones(C_))]
         return E.Ln(float(s1), *[E.ptr(x) for x in t])

@@ -18,6 +18,15 @@
  *   - activations between kernels are int8 codes, row-major [rows][channels]; "rows" = batch*tokens.
  *   - all scales named *_pot are exact powers of two (the reference's PoT observers, minmax.py:247-251);
  *     per-channel PTF scales (ptf.py:51,133) are arbitrary fp32 and are divided by, as the reference does.
+ *
+ * Limits of what is instantiated (everything else returns P2V_E_UNSUPPORTED, at plan creation where the geometry is known):
+ *   - ViT attention: head_dim 32 or 64; tokens per image <= 64 or 193..224 (i.e. 224^2 / 16 and the test geometries; 384^2 is not
+ *     built); Swin window attention: head_dim 32, windows up to 8 x 8;
+ *   - LayerNorm: up to 2048 channels, PTF input masks (in_scale / min in_scale) in {1, 2, 4, 8};
+ *   - p2v_ln.inv_out is MULTIPLIED by (the reference divides by the scale): identical for the power-of-two scales of this path; for any
+ *     other value the 8-bit multiplier M can land one step away on about 1e-5 of the elements;
+ *   - REQUANT epilogues fold 1/scale into the column constants: it must be a power of two;
+ *   - log-int-softmax constants: c_int < 2^24 (qact_attn1 scale >= 2^-11).
  */
 #ifndef P2VIT_H
 #define P2VIT_H
