@@ -43,6 +43,7 @@ struct AttnArgs {
   p2v_attn at;
   int8_t* out;
   int8_t* probs_k;
+  int pshift;           // filled by the launcher: score multiplier = 2^-pshift (>= 1) -> integer requant path; 0 = fp32 path
 };
 
 struct WinAttnArgs {

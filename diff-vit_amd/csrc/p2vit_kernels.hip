@@ -1307,7 +1307,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 typedef short v2i16 __attribute__((ext_vector_type(2)));
 
-template <int HD, int NKP, bool TAP>   // NKP = 32-key pairs covering the tokens (7 for 197); TAP: also write probs_k
+// ISH: the score multiplier qk_scale * s_q1^2 / s_attn is 2^-pshift with pshift >= 1 (head_dim 64: qk_scale = 1/8): the qact_attn1
+// codes come from an integer round-half-even shift instead of the fp32 cvt / mul / rndne / med3 / cvt chain (2.5 VALU per score less)
+template <int HD, int NKP, bool TAP, bool ISH>   // NKP = 32-key pairs covering the tokens (7 for 197); TAP: also write probs_k
 __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
   constexpr int KROWS = NKP * 32;
   constexpr int NKB = NKP * 2;                  // 16-key blocks
@@ -1388,6 +1390,46 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
       s[kb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq, (v4i){0, 0, 0, 0}, 0, 0, 0);
     }
     const bool tail_empty = (NKB - 1) * 16 >= N;     // last 16-key block holds only padding (e.g. N = 197: keys 208..223)
+    long long S = 0;
+    if (ISH) {
+      // codes = clamp(rne(score * 2^-p)): (float)score * 2^-p is exact, so torch.round of it is the integer round-half-even shift
+      // (s + 2^(p-1) - 1 + bit p of s) >> p.  Row max of the codes; d = max - code; padded keys get a code far below every real one.
+      const int p = a.pshift, hm1 = (1 << (p - 1)) - 1;
+      int mx = -100000;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        if (kb == NKB - 1 && tail_empty) continue;       // wave-uniform: no arithmetic for a block of padding
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int sv = s[kb][r];
+          int code = (int)((unsigned)sv + (unsigned)hm1 + (((unsigned)sv >> p) & 1u)) >> p;    // |sv| < 2^21: no overflow
+          code = code < -128 ? -128 : (code > 127 ? 127 : code);
+          if (kb >= NKB - 2) code = (kb * 16 + 4 * g + r) < N ? code : -100000;
+          s[kb][r] = code;
+          mx = code > mx ? code : mx;
+        }
+      }
+      {
+        int o = __shfl_xor(mx, 16);
+        mx = o > mx ? o : mx;
+        o = __shfl_xor(mx, 32);
+        mx = o > mx ? o : mx;
+      }
+      const int mx8 = mx << 3;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        if (kb == NKB - 1 && tail_empty) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int d8;                                          // 8 * (max - code), the byte offset into both tables, in ONE instruction
+          asm("v_mad_i32_i24 %0, %1, -8, %2" : "=v"(d8) : "v"(s[kb][r]), "v"(mx8));      // (hipcc splits mul24(x,-8)+y into shift + sub)
+          if (kb >= NKB - 2) d8 = d8 > 2048 ? 2048 : d8;   // padding -> the sentinel entry
+          s[kb][r] = d8;
+          S += *reinterpret_cast<const long long*>(lutE + d8);
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // keep live ranges short
+      }
+    } else {
     // scores -> NEGATED int8 codes of qact_attn1 (nc = -code) ; row min of nc = -(row max).  Padded keys get +1000.
     int mn = 1000;
 #pragma unroll
@@ -1409,7 +1451,6 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
     }
     // d = max - code = nc - mn in [0, 255]; s[][] := 8*d, the byte offset into both tables (256 = sentinel of padding)
     const int neg8mn = -8 * mn;
-    long long S = 0;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       if (kb == NKB - 1 && tail_empty) continue;
@@ -1421,6 +1462,7 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
         S += *reinterpret_cast<const long long*>(lutE + d8);
       }
       __builtin_amdgcn_sched_barrier(0);                         // keep live ranges short
+    }
     }
     S += __shfl_xor(S, 16);
     S += __shfl_xor(S, 32);
@@ -1893,13 +1935,23 @@ int p2v_launch_layernorm(const LnArgs& a_, hipStream_t st) {
 }
 
 template <int HD, int NKB>
-static int launch_attn_t(const AttnArgs& a, hipStream_t st) {
+static int launch_attn_t(const AttnArgs& a_, hipStream_t st) {
   constexpr int KROWS = NKB * 32;   // NKB here = 32-key pairs
   constexpr size_t smem = (size_t)KROWS * HD + (size_t)HD * (KROWS + 4) * 2 + 258 * 8 + 258 * 8;
-  if (a.probs_k)
-    hipLaunchKernelGGL((k_lis_attention<HD, NKB, true>), dim3(a.B * a.H), dim3(64 * g_attn_waves), smem, st, a);
-  else
-    hipLaunchKernelGGL((k_lis_attention<HD, NKB, false>), dim3(a.B * a.H), dim3(64 * g_attn_waves), smem, st, a);
+  AttnArgs a = a_;
+  {   // score multiplier 2^-p with p >= 1: the integer round-half-even path (|score| <= 64 * 128 * 128 < 2^21, p <= 24)
+    int ex;
+    const float m = a.at.qk_scale * (a.at.s_qkv_sq * a.at.inv_s_attn);
+    a.pshift = (m > 0.f && frexpf(m, &ex) == 0.5f && ex <= 0 && ex >= -23) ? 1 - ex : 0;
+  }
+  const dim3 grid(a.B * a.H), block(64 * g_attn_waves);
+  if (a.probs_k) {
+    if (a.pshift) hipLaunchKernelGGL((k_lis_attention<HD, NKB, true, true>), grid, block, smem, st, a);
+    else hipLaunchKernelGGL((k_lis_attention<HD, NKB, true, false>), grid, block, smem, st, a);
+  } else {
+    if (a.pshift) hipLaunchKernelGGL((k_lis_attention<HD, NKB, false, true>), grid, block, smem, st, a);
+    else hipLaunchKernelGGL((k_lis_attention<HD, NKB, false, false>), grid, block, smem, st, a);
+  }
   CHECK_LAUNCH();
   return 0;
 }
