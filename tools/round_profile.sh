@@ -5,7 +5,7 @@ set -e
 TAG=${1:-rXX}
 R=$GRAFT_REPO_ROOT
 cd $R
-python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+if [ -z "$SKIP_TESTS" ]; then python -m pytest tests -x -q -m gpu 2>&1 | tail -2; fi
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -c 2000 gpurun_out/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
@@ -18,4 +18,4 @@ bash $R/tools/pmc.sh > $R/gpurun_out/${TAG}_pmc.log 2>&1
 python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc > $R/gpurun_out/${TAG}_pmc_summary.txt
 cp $R/gpurun_out/pmc/summary.json $R/gpurun_out/${TAG}_pmc_summary.json
 rm -rf $R/gpurun_out/pmc
-grep -A12 "k_gemm_i8_w4<1>" $R/gpurun_out/${TAG}_pmc_summary.txt | head -30
+grep -A16 "k_ln_gemm<5, 6>" $R/gpurun_out/${TAG}_pmc_summary.txt | head -40
