@@ -166,7 +166,7 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH, help='images per GPU (BASELINE config 2: 256)')
     ap.add_argument('--bits', type=int, default=8, choices=(4, 8))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--streams', type=int, default=2, help='HIP streams the per-GPU batch is sliced over')
+    ap.add_argument('--streams', type=int, default=3, help='HIP streams the per-GPU batch is sliced over (3: one slice of 85-86 images is about one fused LayerNorm+GEMM workgroup per CU)')
     ap.add_argument('--model', default=MODEL, choices=('deit_tiny', 'deit_small', 'deit_base', 'vit_base', 'swin_tiny', 'swin_base'))
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for a rehearsal on one GPU)')
     args = ap.parse_args()
@@ -221,8 +221,8 @@ def main():
     x = base.repeat((B + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
     bits = [args.bits] * (4 * arch['depth'] + 2)
     logits = torch.empty(B, arch['num_classes'], device=dev)
-    # == model(x, bits)[0]; the per-GPU batch runs as two half-batch slices on two HIP streams (images are independent; the kernels of
-    # one slice fill the latency/VALU gaps of the other).  The N-GPU step is the product's data-parallel runner: every rank forwards
+    # == model(x, bits)[0]; the per-GPU batch runs as contiguous slices on their own HIP streams (images are independent; the kernels
+    # of one slice fill the latency/VALU gaps of the others; 3 slices measured best: 92.3 vs 90.3 k img/s at 2, 67.7 k at 4).  The N-GPU step is the product's data-parallel runner: every rank forwards
     # its own shard, then ONE all-gather of the logits -- dp.DataParallelForward, the class the gloo tests exercise.
     runner = dva.dp.DataParallelForward(lambda xs: plan.forward_streams(xs, bits, logits, args.streams), arch['num_classes'])
     out = [None]
