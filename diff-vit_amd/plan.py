@@ -280,7 +280,7 @@ class FrozenPlan:
                 taps['qkv_output'], taps['fc1_output'] = qkv, fc1
         return out
 
-    def forward_streams(self, images, bit_config, out, n_streams=2):
+    def forward_streams(self, images, bit_config, out, n_streams=3):
         """Same result as ``forward``; the batch is cut into ``n_streams`` contiguous slices that run on their own HIP
         streams with their own workspaces.  Images are independent, so this is only a scheduling choice: kernels of one
         slice (e.g. a VALU-bound GELU epilogue) overlap latency- or MFMA-bound phases of another slice's kernels."""

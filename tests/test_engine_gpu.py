@@ -149,6 +149,9 @@ def test_deit_small_full_batch_properties(dva, oracle, synth):
         assert torch.equal(o[32 * rep + 5: 32 * rep + 9], ref4), rep
     one = plan.forward(x, bits).cpu()
     assert torch.equal(one, o)                                      # one stream == two streams
+    out3 = torch.empty(256, 1000, device='cuda')
+    plan.forward_streams(x, bits, out3)                             # the default: three slices (86 + 86 + 84 images)
+    assert torch.equal(out3.cpu(), o)
     assert torch.equal(plan.forward(x[:255], bits).cpu(), o[:255])
     assert len(set(o[:32].argmax(1).tolist())) > 3
 
