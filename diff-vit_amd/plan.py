@@ -295,10 +295,11 @@ class FrozenPlan:
                 self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
                 self._ws_multi = [None] * n_streams
             cur = torch.cuda.current_stream(self.device)
-            step = (B + n_streams - 1) // n_streams
             L = E.lib()
+            q, r = divmod(B, n_streams)          # balanced split: 256 -> 86 + 85 + 85 (an 85-image slice is 510 attention workgroups,
+            lo = hi = 0                          # just under the 512 that are resident at once; 86 images need a second round)
             for i, st in enumerate(self._streams):
-                lo, hi = i * step, min(B, (i + 1) * step)
+                lo, hi = hi, hi + q + (1 if i < r else 0)
                 if lo >= hi:
                     break
                 n = L.p2v_workspace_bytes(self._handle, hi - lo)

@@ -261,7 +261,9 @@ class SwinPlan:
                 gemm(E.EPI_RESID, att, b['proj'], epi_res(b['proj_epi'], x), x2)
                 taps.append((len(ops), p + 'qact2', x2))
                 lnorm(x2, b['ln2'], Cc, ln)
-                gemm(E.EPI_GELU, ln, b['fc1'], epi_req(b['inv_s_fc1']), hid)
+                e_fc1 = epi_req(b['inv_s_fc1'])
+                e_fc1.gelu = E.gelu_table(b['inv_s_fc1'], self.device)       # exact GELU -> qact1 threshold table (cached per scale)
+                gemm(E.EPI_GELU, ln, b['fc1'], e_fc1, hid)
                 gemm(E.EPI_RESID, hid, b['fc2'], epi_res(b['fc2_epi'], x2), x)
                 taps.append((len(ops), p + 'qact4', x))
             if stg['merge'] is not None:
