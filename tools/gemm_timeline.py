@@ -1,9 +1,13 @@
-"""GPU diagnostic: per-workgroup phase stamps of one tiled GEMM launch (fc1 shape)."""
+"""GPU diagnostic (diag build: make -C diff-vit_amd/csrc diag): per-workgroup phase stamps of one register-staged tiled GEMM launch
+(k_gemm_i8_w4, fc1 shape).  The stamps exist only in libp2vit_hip_diag.so; the product library carries none."""
 import ctypes as C, os, sys
+os.environ['P2V_GEMM_STAGES'] = '0'          # the stamped kernel is the register-staged one
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import diff_vit_amd as dva
-E = dva.engine; L = E.lib()
+E = dva.engine
+E.LIB_PATH = os.path.join(ROOT, 'diff-vit_amd', 'csrc', 'libp2vit_hip_diag.so')
+L = E.lib()
 L.p2v_debug_set_gemm_stamps.argtypes = [C.c_void_p]; L.p2v_debug_set_gemm_stamps.restype = None
 M, K, N = 50432, 384, int(sys.argv[1]) if len(sys.argv) > 1 else 1536
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else E.EPI_GELU
