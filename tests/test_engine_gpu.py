@@ -72,6 +72,21 @@ def test_bit_config_and_shape_errors(dva, micro):
         plan.forward(torch.zeros(1, 3, 40, 40, device='cuda'), [8] * 10)
     with pytest.raises(RuntimeError):
         plan.forward(micro['x_ev'], [8] * 10)          # CPU tensor: no fallback
+    # the same checks guard the multi-stream and the profiling entry (they hand raw pointers to the C ABI)
+    out = torch.empty(x.shape[0], 10, device='cuda')
+    for call in (lambda im, bc: plan.forward_streams(im, bc, out), lambda im, bc: plan.profile(im, bc)):
+        with pytest.raises(AssertionError):
+            call(torch.zeros(x.shape[0], 3, 40, 40, device='cuda'), [8] * 10)
+        with pytest.raises(AssertionError):
+            call(torch.zeros(x.shape[0], 1, 32, 32, device='cuda'), [8] * 10)       # channel count
+        with pytest.raises(RuntimeError):
+            call(micro['x_ev'], [8] * 10)
+        with pytest.raises(ValueError):
+            call(x, None)
+    with pytest.raises(AssertionError):
+        plan.forward(torch.zeros(0, 3, 32, 32, device='cuda'), [8] * 10)            # empty batch
+    with pytest.raises(AssertionError):
+        plan.forward_streams(torch.cat([x] * 4), [8] * 10, torch.empty(3, 10, device='cuda'))     # out of the wrong shape
 
 
 # --------------------------------------------------------------------------------------------------
