@@ -1350,23 +1350,35 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
     }
   }
   // stage K rows (swizzled so that a 16-row x 16-byte-chunk fragment read is conflict free) and V^T (bf16)
-  for (int i = tid; i < KROWS * CH; i += (int)blockDim.x) {
-    const int row = i / CH, c = i % CH;
-    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-    if (row < N) {
-      kv = *reinterpret_cast<const uint4*>(base + (long long)row * ld + D + c * 16);
-      vv = *reinterpret_cast<const uint4*>(base + (long long)row * ld + 2 * D + c * 16);
-    }
-    const int sw = (HD == 64) ? (c ^ (((row >> 3) & 1) << 1)) : c;
-    *reinterpret_cast<uint4*>(sK + row * HD + sw * 16) = kv;
-    const unsigned w4[4] = {vv.x, vv.y, vv.z, vv.w};
+  // two chunks per thread and turn: all four global loads are requested before the first LDS store waits for one
+  for (int i0 = tid; i0 < KROWS * CH; i0 += 2 * (int)blockDim.x) {
+    uint4 kv[2], vv[2];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float f = (float)sx8(w4[j >> 2], j & 3);
-      sVt[(c * 16 + j) * VSTRIDE + row] = (unsigned short)(__float_as_uint(f) >> 16);   // exact bf16
+    for (int u = 0; u < 2; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      const int row = i / CH, c = i % CH;
+      kv[u] = make_uint4(0, 0, 0, 0);
+      vv[u] = make_uint4(0, 0, 0, 0);
+      if (i < KROWS * CH && row < N) {
+        kv[u] = *reinterpret_cast<const uint4*>(base + (long long)row * ld + D + c * 16);
+        vv[u] = *reinterpret_cast<const uint4*>(base + (long long)row * ld + 2 * D + c * 16);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      if (i >= KROWS * CH) break;
+      const int row = i / CH, c = i % CH;
+      const int sw = (HD == 64) ? (c ^ (((row >> 3) & 1) << 1)) : c;
+      *reinterpret_cast<uint4*>(sK + row * HD + sw * 16) = kv[u];
+      const unsigned w4[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float f = (float)sx8(w4[j >> 2], j & 3);
+        sVt[(c * 16 + j) * VSTRIDE + row] = (unsigned short)(__float_as_uint(f) >> 16);   // exact bf16
+      }
     }
   }
-  __syncthreads();
 
   // (q@k^T)*scale / s_attn  ==  (acc * qk_scale) * (s_q1^2 / s_attn): the power-of-two factors commute with
   // the single rounding of the *scale product (vit_fquant.py:316-317)
@@ -1375,11 +1387,21 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
   const float nmm = -(a.at.qk_scale * (a.at.s_qkv_sq * a.at.inv_s_attn));
   const int nqb = (N + 15) >> 4;
   const int nwaves = (int)(blockDim.x >> 6);
+  // the Q fragment of a wave's first query block is requested before the barrier and the one of its next block a block ahead: its
+  // global-memory latency overlaps the staging wait / the arithmetic of the current block
+  v4i fq_next = {0, 0, 0, 0};
+  if (g < CH && wave < nqb) {
+    const int qr0 = wave * 16 + l15;
+    fq_next = *reinterpret_cast<const v4i*>(base + (long long)(qr0 < N ? qr0 : N - 1) * ld + g * 16);
+  }
+  __syncthreads();
   for (int qb = wave; qb < nqb; qb += nwaves) {
     const int qrow = qb * 16 + l15;
-    const int qr = qrow < N ? qrow : N - 1;
-    v4i fq = {0, 0, 0, 0};
-    if (g < CH) fq = *reinterpret_cast<const v4i*>(base + (long long)qr * ld + g * 16);
+    const v4i fq = fq_next;
+    if (g < CH && qb + nwaves < nqb) {
+      const int qn = (qb + nwaves) * 16 + l15;
+      fq_next = *reinterpret_cast<const v4i*>(base + (long long)(qn < N ? qn : N - 1) * ld + g * 16);
+    }
     v4i s[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {          // all score MFMAs first: no dependent use behind an MFMA
