@@ -1319,9 +1319,9 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int8_t* sK = reinterpret_cast<int8_t*>(smem);                                  // [KROWS][HD] swizzled
   unsigned short* sVt = reinterpret_cast<unsigned short*>(smem + KROWS * HD);    // [HD][VSTRIDE] bf16
-  // two 8-byte-stride tables addressed by the same byte offset 8*d: exp_int (int64) and {float(exp_int), 1/float(exp_int)}
+  // two 8-byte-stride tables addressed by the same byte offset 8*d: exp_int (int64) and the fp64 reciprocal of float(exp_int)
   unsigned char* lutE = smem + KROWS * HD + HD * VSTRIDE * 2;                      // [257] long long
-  unsigned char* lutFR = lutE + 258 * 8;                                           // [257] float2
+  unsigned char* lutFR = lutE + 258 * 8;                                           // [257] double
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x / a.H, head = blockIdx.x % a.H;
@@ -1341,12 +1341,11 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
     e = e < 0 ? 0 : e;
     const float ef = (float)e;                   // exact: z < 2^24; 1 <= e <= 2^56 (z > 0 on (x0, 0], shift >= 0)
     reinterpret_cast<long long*>(lutE)[tid] = e;
-    // the correctly rounded reciprocal (a bare 1.0f/x may compile to the 1-ulp v_rcp_f32): 1/ef in fp64 is at least
-    // 2^-49 (relative) away from any fp32 rounding boundary, so rounding the fp64 quotient once more is exact
-    reinterpret_cast<float2*>(lutFR)[tid] = make_float2(ef, (float)(1.0 / (double)ef));
+    // the fp64 reciprocal (IEEE division, correctly rounded): the per-score quotient is one fp64 multiply by it, see below
+    reinterpret_cast<double*>(lutFR)[tid] = 1.0 / (double)ef;
     if (tid == 0) {
       reinterpret_cast<long long*>(lutE)[256] = 0;
-      reinterpret_cast<float2*>(lutFR)[256] = make_float2(1.0f, 1.0f);    // sum / 1 >= 2^32 -> k clamps to 16 -> probability 0
+      reinterpret_cast<double*>(lutFR)[256] = 1.0;                          // sum / 1 >= 2^32 -> k clamps to 16 -> probability 0
     }
   }
   // stage K rows (swizzled so that a 16-row x 16-byte-chunk fragment read is conflict free) and V^T (bf16)
@@ -1489,6 +1488,7 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
     S += __shfl_xor(S, 16);
     S += __shfl_xor(S, 32);
     const float Sf = (float)S;                                  // exp_int.sum(-1): exact, then one rounding
+    const double Sd = (double)Sf;
 
     v4f o[NDT];
 #pragma unroll
@@ -1507,14 +1507,13 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
             ratio[e] = 4.0e9f;                                   // -> probability 0
             continue;
           }
-          // round(sum / exp_int), layers.py:370.  Both operands are normal and the quotient is in [1, 2^65): no scaling
-          // or fix-up is needed, and with R the correctly rounded reciprocal two FMA corrections give the correctly
-          // rounded quotient (q1 is faithful; Markstein's theorem for q2).
-          const float2 fr = *reinterpret_cast<const float2*>(lutFR + s[kb][r]);
-          const float q0 = Sf * fr.y;
-          const float q1 = __builtin_fmaf(__builtin_fmaf(-fr.x, q0, Sf), fr.y, q0);
-          const float q2 = __builtin_fmaf(__builtin_fmaf(-fr.x, q1, Sf), fr.y, q1);
-          ratio[e] = rintf(q2);
+          // round(sum / exp_int), layers.py:370: the correctly rounded fp32 quotient from ONE fp64 multiply and one conversion.
+          // Sf = A 2^a and exp_int = B 2^b with integers A, B < 2^24, so A/B lies at least 2^-49 (relative) away from every
+          // fp32 rounding boundary (|A - mB| is a non-zero multiple of the boundary's unit, B < 2^24) and is never one itself
+          // (a 25-bit odd m times B has more than 24 bits); Sd * RN64(1/exp_int) is within 2^-52 of A/B, so converting it to
+          // fp32 rounds to the same side.  (v_mul_f64 + v_cvt_f32_f64 replace v_mul_f32 + four 3-source v_fma_f32.)
+          const double rd = *reinterpret_cast<const double*>(lutFR + s[kb][r]);
+          ratio[e] = rintf((float)(Sd * rd));
           if (TAP && s[kb][r] < 2048 && qrow < N) {
             int k = (int)((__float_as_uint(ratio[e]) + 0x00400000u) >> 23) - 127;   // log_round, layers.py:323-329
             a.probs_k[(((long long)b * a.H + head) * N + qrow) * N + kb * 16 + 4 * g + r] = (int8_t)(k > 16 ? 16 : k);
@@ -1579,7 +1578,7 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
   __shared__ int8_t sT[4][232];                                               // bias-table column of the head ((2*8-1)^2 = 225 max)
   __shared__ unsigned short sMeta[WA_KEYS + 16];                               // per token: lin (y*(2ws-1)+x) | region << 10
   __shared__ long long lutE[258];
-  __shared__ float2 lutFR[258];
+  __shared__ double lutFR[258];                                                // fp64 reciprocal of float(exp_int)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int ws = a.wa.ws, N = ws * ws, nW = a.wa.n_windows;
   const int hgroups = (a.H + 3) >> 2;
@@ -1601,7 +1600,7 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
     if (t == 257) e = 0;
     const float ef = t == 257 ? 1.0f : (float)e;
     lutE[t] = e;
-    lutFR[t] = make_float2(ef, (float)(1.0 / (double)ef));
+    lutFR[t] = 1.0 / (double)ef;
   }
   if (tid < WA_KEYS + 16) {
     const int t = tid < N ? tid : 0;
@@ -1712,6 +1711,7 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
     S += __shfl_xor(S, 16);
     S += __shfl_xor(S, 32);
     const float Sf = (float)S;
+    const double Sd = (double)Sf;
     v4f o[2] = {(v4f){0.f, 0.f, 0.f, 0.f}, (v4f){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -1727,11 +1727,7 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
             hw2[e] = 0u;
             continue;
           }
-          const float2 fr = lutFR[s1[kb][r]];
-          const float r0 = Sf * fr.y;
-          const float r1 = __builtin_fmaf(__builtin_fmaf(-fr.x, r0, Sf), fr.y, r0);
-          const float r2 = __builtin_fmaf(__builtin_fmaf(-fr.x, r1, Sf), fr.y, r1);
-          const float ratio = rintf(r2);
+          const float ratio = rintf((float)(Sd * lutFR[s1[kb][r]]));       // correctly rounded fp32 quotient, as in k_lis_attention
           int k = (int)((__float_as_uint(ratio) + 0x00400000u) >> 23) - 127;
           k = k > 16 ? 16 : k;
           hw2[e] = (k < 16 && s1[kb][r] != 257) ? (unsigned)(127 - k) << 7 : 0u;

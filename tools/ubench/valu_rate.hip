@@ -8,6 +8,7 @@ template <int OP>
 __global__ void k(float* out, float a, float b, int n) {
   float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
   f2 p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7}, pa = {a, a}, pb = {b, b};
+  double dd0 = x0, dd1 = x1, dd2 = x2, dd3 = x3, da = a;
   long long t0 = clock64();
   for (int i = 0; i < n; ++i) {
     if (OP == 0) {  // 8 independent v_fma_f32
@@ -41,6 +42,16 @@ __global__ void k(float* out, float a, float b, int n) {
     } else if (OP == 9) {  // dependent chain of 4 plain ops per value (ILP 8)
       x0 = rintf(fmaxf(x0 * a, b) - b); x1 = rintf(fmaxf(x1 * a, b) - b); x2 = rintf(fmaxf(x2 * a, b) - b); x3 = rintf(fmaxf(x3 * a, b) - b);
       x4 = rintf(fmaxf(x4 * a, b) - b); x5 = rintf(fmaxf(x5 * a, b) - b); x6 = rintf(fmaxf(x6 * a, b) - b); x7 = rintf(fmaxf(x7 * a, b) - b);
+    } else if (OP == 11) {  // fp64 multiply + convert to fp32 (the quotient chain candidate): 2 instructions per value
+      asm volatile("v_mul_f64 %0, %1, %2" : "=v"(dd0) : "v"(dd0), "v"(da));
+      asm volatile("v_mul_f64 %0, %1, %2" : "=v"(dd1) : "v"(dd1), "v"(da));
+      asm volatile("v_mul_f64 %0, %1, %2" : "=v"(dd2) : "v"(dd2), "v"(da));
+      asm volatile("v_mul_f64 %0, %1, %2" : "=v"(dd3) : "v"(dd3), "v"(da));
+    } else if (OP == 12) {  // v_cvt_f32_f64 x4
+      asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x0) : "v"(dd0));
+      asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x1) : "v"(dd1));
+      asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x2) : "v"(dd2));
+      asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x3) : "v"(dd3));
     } else if (OP == 10) {  // same chain with ILP 2 only
       x0 = rintf(fmaxf(x0 * a, b) - b); x1 = rintf(fmaxf(x1 * a, b) - b);
       x0 = rintf(fmaxf(x0 * a, b) - b); x1 = rintf(fmaxf(x1 * a, b) - b);
@@ -49,7 +60,7 @@ __global__ void k(float* out, float a, float b, int n) {
     }
   }
   long long t1 = clock64();
-  float s = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+  float s = (float)(dd0 + dd1 + dd2 + dd3) + x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
   if (s == 12345.678f) out[0] = s;
   if (threadIdx.x == 0 && blockIdx.x == 0) out[1 + OP] = (float)(t1 - t0) / n;
 }
@@ -66,7 +77,7 @@ int main() {
   float* d; hipMalloc(&d, 128); hipMemset(d, 0, 128);
   run<0>("v_fma_f32 x8", 8, d); run<1>("v_pk_fma_f32 x4", 4, d); run<5>("v_pk_mul_f32 x4", 4, d);
   run<2>("mul+rndne x8", 16, d); run<3>("v_exp_f32 x8", 8, d); run<4>("cvt,add,cvt x8", 24, d);
-  run<6>("v_fmaak literal x8", 8, d); run<7>("v_fma 3 vgpr x8", 8, d); run<8>("cmp+cndmask+mul x8", 24, d); run<9>("chain4 ILP8", 32, d); run<10>("chain4 ILP2", 32, d);
+  run<6>("v_fmaak literal x8", 8, d); run<7>("v_fma 3 vgpr x8", 8, d); run<8>("cmp+cndmask+mul x8", 24, d); run<9>("chain4 ILP8", 32, d); run<10>("chain4 ILP2", 32, d); run<11>("v_mul_f64 x4", 4, d); run<12>("v_cvt_f32_f64 x4", 4, d);
   // wall-clock rate: fma
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int wps = 1; wps <= 4; wps *= 2) {
