@@ -1049,22 +1049,22 @@ __device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane
       const float p4[4] = {L.pm[i].x, L.pm[i].y, L.pm[i].z, L.pm[i].w};
       float q[4];
 #pragma unroll
-      for (int j = 0; j < 4; j += 2) {   // two channels at a time: the multiplies, the subtraction and the fma are v_pk_*_f32
-        const v2f g2 = {g4[j], g4[j + 1]}, b2 = {b4[j], b4[j + 1]}, p2 = {p4[j], p4[j + 1]}, x2 = {xq[i][j], xq[i][j + 1]};
-        const v2f A2 = (v2f){rs, rs} * g2;
-        const v2f t2 = b2 - (v2f){mos, mos} * g2;
+      for (int j = 0; j < 4; j += 2) {   // two channels at a time: only the 3-source fma is packed (measured on gfx950, tools/ubench/valu_rate:
+        // a wave issues a 2-source fp32 op every ~4.9 cycles, a v_pk_mul/add_f32 every ~13, a 3-source v_fma_f32 every ~9.5, v_pk_fma_f32 ~13)
         v2f T2, Bq2;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const unsigned Ab = __float_as_uint(A2[e]);
+          const float A = rs * g4[j + e];
+          const float t = b4[j + e] - mos * g4[j + e];
+          const unsigned Ab = __float_as_uint(A);
           T2[e] = __uint_as_float(Ab & 0xFFFF0000u);                              // sign * M * 2^-N
           const int N = 134 - (int)((Ab >> 23) & 255u);                           // in [0, 31] by the range test
-          Bq2[e] = ldexpf(rintf(ldexpf(t2[e], N)), -N);                           // Bv * 2^-N
+          Bq2[e] = ldexpf(rintf(ldexpf(t, N)), -N);                               // Bv * 2^-N
         }
+        const v2f x2 = {xq[i][j], xq[i][j + 1]};
         const v2f o2 = __builtin_elementwise_fma(T2, x2, Bq2);
-        const v2f q2 = (v2f){rintf(o2[0]), rintf(o2[1])} * p2;
-        q[j] = rintf(q2[0]);
-        q[j + 1] = rintf(q2[1]);
+        q[j] = rintf(rintf(o2[0]) * p4[j]);
+        q[j + 1] = rintf(rintf(o2[1]) * p4[j + 1]);
       }
       outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
     }
@@ -1193,20 +1193,22 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < NI; ++i) wf[i] = __builtin_bit_cast(v4i, wsrc[i * 64]);
 
-  // ---- the 64 rows of the residual stream: one row per half wave, 8 rows each, every load requested up front
+  // ---- the 64 rows of the residual stream: one row per half wave, 8 rows each, two rows in flight ahead of the two being normalised
   constexpr int RPH = LG_BM / 8;                                       // rows per half wave
+  static_assert(RPH % 2 == 0, "rows are processed in pairs");
   const int hw = tid >> 5;
-  unsigned win[RPH][NCH];
-#pragma unroll
-  for (int r = 0; r < RPH; ++r) {
+  auto load_row = [&](int r, unsigned (&w)[NCH]) {
     long long row = (long long)m0 + hw * RPH + r;
     row = row < a.rows ? row : a.rows - 1;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = (l31 + 32 * i) * 4;
-      win[r][i] = *reinterpret_cast<const unsigned*>(a.x + row * a.row_stride + (c < C ? c : 0));
+      w[i] = *reinterpret_cast<const unsigned*>(a.x + row * a.row_stride + (c < C ? c : 0));
     }
-  }
+  };
+  unsigned win[2][NCH];
+  load_row(0, win[0]);
+  load_row(1, win[1]);
   // ---- per-column constants of the whole layer (REQUANT: 2^e folded in, see gemm_stage_epilogue) and the GELU table
   {
     const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : 1.0f;
@@ -1230,26 +1232,36 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
     int* sM = reinterpret_cast<int*>(sP + NCH * 128);
     LnLane<NCH> L;
     ln_prepare<NCH, 32>(a.ln, C, a.force_generic != 0, sG, sB, sP, sM, tid, 256, L);
-#pragma unroll 2
-    for (int r = 0; r < RPH; ++r) {
-      const int lrow = hw * RPH + r;
-      unsigned wcur[NCH], outw[NCH];
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        unsigned v = win[0][i];
-#pragma unroll
-        for (int rr = 1; rr < RPH; ++rr) v = r == rr ? win[rr][i] : v;   // register select: the row loop stays (mostly) rolled: code size
-        wcur[i] = L.on[i] ? v : 0u;
+#pragma unroll 1
+    for (int r = 0; r < RPH; r += 2) {
+      unsigned wnext[2][NCH];
+      if (r + 2 < RPH) {
+        load_row(r + 2, wnext[0]);
+        load_row(r + 3, wnext[1]);
       }
-      ln_row<NCH, 32>(wcur, L, a.ln, C, l31, outw);
-      const long long row = (long long)m0 + lrow;
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        const int c = (l31 + 32 * i) * 4;
-        if (c < KT * GBK)      // channels past C inside the last k-tile are zero
-          *reinterpret_cast<unsigned*>(panel + (c >> 6) * (LG_BM * GBK) + lrow * GBK + ((((c & 63) >> 4) ^ ((lrow >> 2) & 3)) << 4) + (c & 15)) =
-              L.on[i] ? outw[i] : 0u;
-        if (a.out && L.on[i] && row < a.rows) *reinterpret_cast<unsigned*>(a.out + row * a.out_stride + c) = outw[i];
+      for (int u = 0; u < 2; ++u) {
+        const int lrow = hw * RPH + r + u;
+        unsigned wcur[NCH], outw[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) wcur[i] = L.on[i] ? win[u][i] : 0u;
+        ln_row<NCH, 32>(wcur, L, a.ln, C, l31, outw);
+        const long long row = (long long)m0 + lrow;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = (l31 + 32 * i) * 4;
+          if (c < KT * GBK)      // channels past C inside the last k-tile are zero
+            *reinterpret_cast<unsigned*>(panel + (c >> 6) * (LG_BM * GBK) + lrow * GBK + ((((c & 63) >> 4) ^ ((lrow >> 2) & 3)) << 4) + (c & 15)) =
+                L.on[i] ? outw[i] : 0u;
+          if (a.out && L.on[i] && row < a.rows) *reinterpret_cast<unsigned*>(a.out + row * a.out_stride + c) = outw[i];
+        }
+      }
+      if (r + 2 < RPH) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          win[0][i] = wnext[0][i];
+          win[1][i] = wnext[1][i];
+        }
       }
     }
   }
