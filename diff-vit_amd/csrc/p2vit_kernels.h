@@ -44,6 +44,9 @@ struct AttnArgs {
   int8_t* out;
   int8_t* probs_k;
   int pshift;           // filled by the launcher: score multiplier = 2^-pshift (>= 1) -> integer requant path; 0 = fp32 path
+#ifdef P2V_DIAG
+  unsigned long long* stamps;   // diagnostic build only: 16 cycle stamps per workgroup (wave 0) or null
+#endif
 };
 
 struct WinAttnArgs {

@@ -1321,6 +1321,15 @@ typedef short v2i16 __attribute__((ext_vector_type(2)));
 
 // ISH: the score multiplier qk_scale * s_q1^2 / s_attn is 2^-pshift with pshift >= 1 (head_dim 64: qk_scale = 1/8): the qact_attn1
 // codes come from an integer round-half-even shift instead of the fp32 cvt / mul / rndne / med3 / cvt chain (2.5 VALU per score less)
+#ifdef P2V_DIAG
+extern unsigned long long* g_gemm_stamps;
+#define AT_STAMP(slot)                                                                                             \
+  do {                                                                                                             \
+    if (a.stamps && threadIdx.x == 0 && (slot) < 16) a.stamps[(long long)blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define AT_STAMP(slot) do { } while (0)
+#endif
 template <int HD, int NKP, bool TAP, bool ISH>   // NKP = 32-key pairs covering the tokens (7 for 197); TAP: also write probs_k
 __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
   constexpr int KROWS = NKP * 32;
@@ -1334,11 +1343,17 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
   // two 8-byte-stride tables addressed by the same byte offset 8*d: exp_int (int64) and the fp64 reciprocal of float(exp_int)
   unsigned char* lutE = smem + KROWS * HD + HD * VSTRIDE * 2;                      // [257] long long
   unsigned char* lutFR = lutE + 258 * 8;                                           // [257] double
+  // the score slots hold ABSOLUTE LDS byte addresses of their exp_int entry (table base folded into the per-row constant of the
+  // subtraction): the gathers need no address arithmetic (hipcc otherwise adds the zero base of the dynamic LDS block per element)
+  typedef __attribute__((address_space(3))) const long long* lds_i64p;
+  typedef __attribute__((address_space(3))) const double* lds_f64p;
+  const int ebase = (int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lutE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.x / a.H, head = blockIdx.x % a.H;
   const int N = a.N, D = a.H * HD, ld = 3 * D;
   const int8_t* base = a.qkv + (long long)b * N * ld + head * HD;
+  AT_STAMP(0);
 
   // exp table: d = max - score -> exp_int = z * 2^(32-q)       (int_exp / int_polynomial, layers.py:334-358)
   // entry 256 is the sentinel of padded keys: contributes 0 to the sum and maps to probability 0.
@@ -1361,6 +1376,7 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
     }
   }
   // stage K rows (swizzled so that a 16-row x 16-byte-chunk fragment read is conflict free) and V^T (bf16)
+  AT_STAMP(1);
   // two chunks per thread and turn: all four global loads are requested before the first LDS store waits for one
   for (int i0 = tid; i0 < KROWS * CH; i0 += 2 * (int)blockDim.x) {
     uint4 kv[2], vv[2];
@@ -1400,12 +1416,15 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
   const int nwaves = (int)(blockDim.x >> 6);
   // the Q fragment of a wave's first query block is requested before the barrier and the one of its next block a block ahead: its
   // global-memory latency overlaps the staging wait / the arithmetic of the current block
+  AT_STAMP(2);
   v4i fq_next = {0, 0, 0, 0};
   if (g < CH && wave < nqb) {
     const int qr0 = wave * 16 + l15;
     fq_next = *reinterpret_cast<const v4i*>(base + (long long)(qr0 < N ? qr0 : N - 1) * ld + g * 16);
   }
   __syncthreads();
+  AT_STAMP(3);
+  [[maybe_unused]] int stamp_base = 4;
   for (int qb = wave; qb < nqb; qb += nwaves) {
     const int qrow = qb * 16 + l15;
     const v4i fq = fq_next;
@@ -1423,6 +1442,10 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
       s[kb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq, (v4i){0, 0, 0, 0}, 0, 0, 0);
     }
     const bool tail_empty = (NKB - 1) * 16 >= N;     // last 16-key block holds only padding (e.g. N = 197: keys 208..223)
+#ifdef P2V_DIAG
+    asm volatile("s_nop 0" :: "v"(s[NKB - 1][0]));       // the stamp below waits for the last score MFMA
+#endif
+    AT_STAMP(stamp_base);
     long long S = 0;
     if (ISH) {
       // codes = clamp(rne(score * 2^-p)): (float)score * 2^-p is exact, so torch.round of it is the integer round-half-even shift
@@ -1448,7 +1471,7 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
         o = __shfl_xor(mx, 32);
         mx = o > mx ? o : mx;
       }
-      const int mx8 = mx << 3;
+      const int mx8 = (mx << 3) + ebase;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         if (kb == NKB - 1 && tail_empty) continue;
@@ -1456,9 +1479,9 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
         for (int r = 0; r < 4; ++r) {
           int d8;                                          // 8 * (max - code), the byte offset into both tables, in ONE instruction
           asm("v_mad_i32_i24 %0, %1, -8, %2" : "=v"(d8) : "v"(s[kb][r]), "v"(mx8));      // (hipcc splits mul24(x,-8)+y into shift + sub)
-          if (kb >= NKB - 2) d8 = d8 > 2048 ? 2048 : d8;   // padding -> the sentinel entry
+          if (kb >= NKB - 2) d8 = d8 > ebase + 2048 ? ebase + 2048 : d8;   // padding -> the sentinel entry
           s[kb][r] = d8;
-          S += *reinterpret_cast<const long long*>(lutE + d8);
+          S += *(lds_i64p)(uintptr_t)(unsigned)d8;
         }
         __builtin_amdgcn_sched_barrier(0);                         // keep live ranges short
       }
@@ -1483,16 +1506,16 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
       mn = o < mn ? o : mn;
     }
     // d = max - code = nc - mn in [0, 255]; s[][] := 8*d, the byte offset into both tables (256 = sentinel of padding)
-    const int neg8mn = -8 * mn;
+    const int neg8mn = -8 * mn + ebase;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       if (kb == NKB - 1 && tail_empty) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int d8 = (s[kb][r] << 3) + neg8mn;
-        if (kb >= NKB - 2) d8 = d8 > 2048 ? 2048 : d8;
+        if (kb >= NKB - 2) d8 = d8 > ebase + 2048 ? ebase + 2048 : d8;
         s[kb][r] = d8;
-        S += *reinterpret_cast<const long long*>(lutE + d8);
+        S += *(lds_i64p)(uintptr_t)(unsigned)d8;
       }
       __builtin_amdgcn_sched_barrier(0);                         // keep live ranges short
     }
@@ -1501,6 +1524,7 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
     S += __shfl_xor(S, 32);
     const float Sf = (float)S;                                  // exp_int.sum(-1): exact, then one rounding
     const double Sd = (double)Sf;
+    AT_STAMP(stamp_base + 1);
 
     v4f o[NDT];
 #pragma unroll
@@ -1524,9 +1548,9 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
           // fp32 rounding boundary (|A - mB| is a non-zero multiple of the boundary's unit, B < 2^24) and is never one itself
           // (a 25-bit odd m times B has more than 24 bits); Sd * RN64(1/exp_int) is within 2^-52 of A/B, so converting it to
           // fp32 rounds to the same side.  (v_mul_f64 + v_cvt_f32_f64 replace v_mul_f32 + four 3-source v_fma_f32.)
-          const double rd = *reinterpret_cast<const double*>(lutFR + s[kb][r]);
+          const double rd = ((lds_f64p)(uintptr_t)(unsigned)s[kb][r])[258];          // the reciprocal table starts 258 entries behind exp_int
           ratio[e] = rintf((float)(Sd * rd));
-          if (TAP && s[kb][r] < 2048 && qrow < N) {
+          if (TAP && s[kb][r] < ebase + 2048 && qrow < N) {
             int k = (int)((__float_as_uint(ratio[e]) + 0x00400000u) >> 23) - 127;   // log_round, layers.py:323-329
             a.probs_k[(((long long)b * a.H + head) * N + qrow) * N + kb * 16 + 4 * g + r] = (int8_t)(k > 16 ? 16 : k);
           }
@@ -1552,6 +1576,10 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     // qact2: (attn @ v) / s  with attn@v = O * s_q1   (vit_fquant.py:325-326); lane owns channels 16dt+4g..+3
+#ifdef P2V_DIAG
+    asm volatile("s_nop 0" :: "v"(o[NDT - 1][0]));
+#endif
+    AT_STAMP(stamp_base + 2);
     if (qrow < N) {
       int8_t* dst = a.out + ((long long)b * N + qrow) * D + head * HD + 4 * g;
 #pragma unroll
@@ -1559,6 +1587,8 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
         *reinterpret_cast<unsigned*>(dst + dt * 16) =
             pack4_sat(rintf(o[dt][0] * a.at.av_mul), rintf(o[dt][1] * a.at.av_mul), rintf(o[dt][2] * a.at.av_mul), rintf(o[dt][3] * a.at.av_mul));
     }
+    AT_STAMP(stamp_base + 3);
+    stamp_base += 4;
   }
 }
 
@@ -1974,6 +2004,9 @@ static int launch_attn_t(const AttnArgs& a_, hipStream_t st) {
     const float m = a.at.qk_scale * (a.at.s_qkv_sq * a.at.inv_s_attn);
     a.pshift = (m > 0.f && frexpf(m, &ex) == 0.5f && ex <= 0 && ex >= -23) ? 1 - ex : 0;
   }
+#ifdef P2V_DIAG
+  a.stamps = g_gemm_stamps;
+#endif
   const dim3 grid(a.B * a.H), block(64 * g_attn_waves);
   if (a.probs_k) {
     if (a.pshift) hipLaunchKernelGGL((k_lis_attention<HD, NKB, true, true>), grid, block, smem, st, a);
