@@ -1,6 +1,6 @@
 #!/bin/bash
-# rocprofv3 PMC passes over a short single-stream bench run at the launch size of the default bench (one slice = 128 images:
-# the same kernels and shapes as the two-stream run, without a concurrent kernel polluting the counters) (counters in their own runs: no trace domains besides kernel-trace)
+# rocprofv3 PMC passes over a short single-stream bench run at the launch size of the default bench (one slice of the default run, PMC_BATCH images:
+# the same kernels and shapes as the sliced run, without a concurrent kernel polluting the counters) (counters in their own runs: no trace domains besides kernel-trace)
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
