@@ -1050,7 +1050,7 @@ __device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane
       float q[4];
 #pragma unroll
       for (int j = 0; j < 4; j += 2) {   // two channels at a time: only the 3-source fma is packed (measured on gfx950, tools/ubench/valu_rate:
-        // a wave issues a 2-source fp32 op every ~4.9 cycles, a v_pk_mul/add_f32 every ~13, a 3-source v_fma_f32 every ~9.5, v_pk_fma_f32 ~13)
+        // a wave alone on its SIMD issues a 2-source fp32 op every ~4.9 cycles, a v_pk_mul/add_f32 every ~13, a 3-source v_fma_f32 every ~8, v_pk_fma_f32 ~13)
         v2f T2, Bq2;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {

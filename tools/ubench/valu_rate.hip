@@ -62,10 +62,12 @@ __global__ void k(float* out, float a, float b, int n) {
   long long t1 = clock64();
   float s = (float)(dd0 + dd1 + dd2 + dd3) + x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
   if (s == 12345.678f) out[0] = s;
-  if (threadIdx.x == 0 && blockIdx.x == 0) out[1 + OP] = (float)(t1 - t0) / n;
+  // the slowest wave of the grid: waves of one SIMD are served oldest first, so wave 0 alone would show the single-wave rate
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out) + 1 + OP, __float_as_uint((float)(t1 - t0) / n));
 }
 template <int OP> void run(const char* name, int instr_per_iter, float* d) {
   for (int wps = 1; wps <= 4; wps *= 2) {   // waves per SIMD: block of 256*wps threads, one block per CU
+    hipMemset(d, 0, 128);
     hipLaunchKernelGGL(k<OP>, dim3(256), dim3(256 * wps), 0, 0, d, 1.0001f, 0.5f, ITER);
     hipDeviceSynchronize();
     float h[16]; hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
