@@ -1281,7 +1281,9 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
 
   for (int j = 0; j < tiles_n; ++j) {
     const bool more = j + 1 < tiles_n;                                   // wave-uniform
-    const uint4* wnext = wsrc + (long long)(j + 1) * 4 * NI * 64;
+    // the fragment loads are unconditional (the last tile re-requests itself): with a branch around them hipcc cannot count the
+    // outstanding requests and waits vmcnt(0) at the top of every tile - i.e. for the output STORES of the tile before
+    const uint4* wnext = wsrc + (long long)(more ? j + 1 : j) * 4 * NI * 64;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int off = (i >> 1) * (LG_BM * GBK) + (i & 1) * xks;
@@ -1289,7 +1291,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
       const v4i xb = *reinterpret_cast<const v4i*>(pXb + off);
       acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xa, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xb, acc[1], 0, 0, 0);
-      if (more) wf[i] = __builtin_bit_cast(v4i, wnext[i * 64]);          // the fragment of the next column tile, a tile ahead of its use
+      wf[i] = __builtin_bit_cast(v4i, wnext[i * 64]);                    // the fragment of the next column tile, a tile ahead of its use
     }
     LG_STAMP(4 + 2 * j);
     const EpiLds* e = reinterpret_cast<const EpiLds*>(consts + j * 2 * GBN);
