@@ -1582,8 +1582,12 @@ __global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
     asm volatile("s_nop 0" :: "v"(o[NDT - 1][0]));
 #endif
     AT_STAMP(stamp_base + 2);
-    if (qrow < N) {
-      int8_t* dst = a.out + ((long long)b * N + qrow) * D + head * HD + 4 * g;
+    {
+      // unconditional stores: a padding query row (qrow >= N) was computed from the Q fragment of row N-1, so its values ARE row N-1's
+      // and it may store them there.  With the stores behind a branch hipcc cannot count them and waits vmcnt(0) - for these
+      // stores - before the next block may use its prefetched Q fragment
+      const int qs = qrow < N ? qrow : N - 1;
+      int8_t* dst = a.out + ((long long)b * N + qs) * D + head * HD + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt)
         *reinterpret_cast<unsigned*>(dst + dt * 16) =
