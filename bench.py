@@ -87,12 +87,12 @@ def bench_swin(args, dva, dev, world, rank):
     Bl = (B + n_sl - 1) // n_sl
     prof = plan.profile(x[:Bl])
     prof = plan.profile(x[:Bl])
-    rec = plan._recorded[(Bl, 0)]
+    rec = plan._recorded[(Bl, 0, True)]
     kinds = {}
     for i, (kind, epi, ms) in enumerate(prof):
         o = rec['ops'][i]
-        name = kind + ('_' + {0: 'requant', 1: 'gelu', 2: 'resid', 4: 'head'}.get(epi, str(epi)) if kind == 'gemm' else '')
-        ops = 2.0 * o.M * o.K * o.N if kind == 'gemm' else (4.0 * o.i0 * o.i1 * 49 * 32 * o.i2 if kind == 'window_attention' else 0.0)
+        name = kind + ('_' + {0: 'requant', 1: 'gelu', 2: 'resid', 4: 'head'}.get(epi, str(epi)) if kind in ('gemm', 'ln_gemm') else '')
+        ops = 2.0 * o.M * o.K * o.N if kind in ('gemm', 'ln_gemm') else (4.0 * o.i0 * o.i1 * 49 * 32 * o.i2 if kind == 'window_attention' else 0.0)
         k = kinds.setdefault(name, [0, 0.0, 0.0])
         k[0] += 1; k[1] += ms; k[2] += ops
     dom = max(kinds, key=lambda n: kinds[n][1])

@@ -412,6 +412,11 @@ int p2v_ln_gemm_i8(int kind, const int8_t* x, long long row_stride, int M, int C
   return run_ln_gemm(kind, a, *lin, *epi, N, out, (hipStream_t)stream);
 }
 
+int p2v_ln_gemm_fusable(int kind, int C, int N, int cells) {
+  read_env_once();
+  return (C > 0 && N > 0 && cells >= 0 && cells <= 4096 && p2v_ln_gemm_supported(kind, C, N, cells)) ? 1 : 0;
+}
+
 int p2v_lis_attention(const int8_t* qkv, int batch, int tokens, int heads, int head_dim, const p2v_attn* at, int8_t* out,
                       int8_t* probs_k, void* stream) {
   if (!qkv || !at || !out) return fail(P2V_E_ARG, "p2v_lis_attention: null argument");
@@ -475,6 +480,8 @@ static int run_one_op(const p2v_op& o, void* stream) {
       return p2v_patch_merge_gather((const int8_t*)o.in, o.i0, o.i1, o.i2, o.i3, (int8_t*)o.out, stream);
     case P2V_OP_AVGPOOL:
       return p2v_avgpool_quant((const int8_t*)o.in, o.i0, o.i1, o.i2, o.f0, o.f1, (int8_t*)o.out, stream);
+    case P2V_OP_LN_GEMM:
+      return p2v_ln_gemm_i8(o.epi, (const int8_t*)o.in, o.lda, o.M, o.K, &o.ln, o.N, &o.lin, &o.ep, (int8_t*)o.out, o.ldo, nullptr, stream);
     default:
       return fail(P2V_E_ARG, "p2v_run_ops: unknown op kind %d", o.kind);
   }

@@ -59,7 +59,7 @@ class Block(C.Structure):
                 ('inv_s_fc1', _f), ('gelu_fc1', GeluTab), ('fc2_epi', Epilogue)]
 
 
-OP_PATCHIFY, OP_GEMM, OP_LAYERNORM, OP_WINATTN, OP_MERGE, OP_AVGPOOL = range(6)
+OP_PATCHIFY, OP_GEMM, OP_LAYERNORM, OP_WINATTN, OP_MERGE, OP_AVGPOOL, OP_LN_GEMM = range(7)
 
 
 class Op(C.Structure):
@@ -111,6 +111,8 @@ def lib():
     L.p2v_int_layernorm.argtypes = [_p, _ll, _i, _i, C.POINTER(Ln), _p, _ll, _p]
     L.p2v_lis_attention.argtypes = [_p, _i, _i, _i, _i, C.POINTER(Attn), _p, _p, _p]
     L.p2v_ln_gemm_i8.argtypes = [_i, _p, _ll, _i, _i, C.POINTER(Ln), _i, C.POINTER(Linear), C.POINTER(Epilogue), _p, _i, _p, _p]
+    L.p2v_ln_gemm_fusable.argtypes = [_i, _i, _i, _i]
+    L.p2v_ln_gemm_fusable.restype = _i
     L.p2v_run_ops.argtypes = [C.POINTER(Op), _i, _p]
     L.p2v_run_ops_profile.argtypes = [C.POINTER(Op), _i, _p, C.POINTER(C.c_float)]
     L.p2v_patch_merge_gather.argtypes = [_p, _i, _i, _i, _i, _p, _p]

@@ -70,8 +70,9 @@ class SwinPlan:
             raise NotImplementedError('%s: the engine needs a power-of-two layer-wise scale, got %r' % (name, self.c[name][:4]))
         return s
 
-    def _linear(self, name, s_x, bias=True, k_pad=None):
-        """int8-stored weight codes [n_pad][k_pad], colscale = s_x * s_w, bias."""
+    def _linear(self, name, s_x, bias=True, k_pad=None, frag=False):
+        """int8-stored weight codes [n_pad][k_pad], colscale = s_x * s_w, bias; ``frag``: also the MFMA-fragment-order copy the fused
+        LayerNorm+GEMM kernel streams (qkv / fc1 of stages up to 384 channels)."""
         bt = 'int%d' % self.bits
         w = self.W[name + '.weight']
         w2 = w.reshape(w.shape[0], -1)
@@ -88,7 +89,8 @@ class SwinPlan:
         if bias:
             b[:N] = self.W[name + '.bias']
         d = dict(w=self._dev(wp, torch.int8), cs=self._dev(cs), b=self._dev(b), N=N, K=kp)
-        d['lin'] = E.Linear(E.ptr(d['w']), E.ptr(d['cs']), E.ptr(d['b']))
+        d['wf'] = self._dev(E.fragment_order(wp), torch.int8) if frag else None
+        d['lin'] = E.Linear(E.ptr(d['w']), E.ptr(d['cs']), E.ptr(d['b']), E.ptr(d['wf']) if frag else None, 0)
         return d
 
     def _ln(self, prefix, s_in_vec, s_out, C_):
@@ -135,7 +137,7 @@ class SwinPlan:
                 b = dict(C=Cc, heads=heads, H=H, ws=wsz, shift=shift)
                 b['ln1'] = self._ln(p + 'norm1', s_res, s1, Cc)
                 s_q1 = self._pot(p + 'attn.qact1')
-                b['qkv'] = self._linear(p + 'attn.qkv', s1)
+                b['qkv'] = self._linear(p + 'attn.qkv', s1, frag=Cc <= 384)
                 b['inv_s_qkv'] = 1.0 / s_q1
                 s_q2 = self._pot(p + 'attn.qact2')
                 s_q3 = self._pot(p + 'attn.qact3')
@@ -153,7 +155,7 @@ class SwinPlan:
                 b['proj_epi'] = self._resid_epi(self._pot(p + 'attn.qact4'), s_res, s_b2, Cc)
                 s3 = self._pot(p + 'qact3')
                 b['ln2'] = self._ln(p + 'norm2', s_b2, s3, Cc)
-                b['fc1'] = self._linear(p + 'mlp.fc1', s3)
+                b['fc1'] = self._linear(p + 'mlp.fc1', s3, frag=Cc <= 384)
                 s_m1 = self._pot(p + 'mlp.qact1')
                 b['inv_s_fc1'] = 1.0 / s_m1
                 b['fc2'] = self._linear(p + 'mlp.fc2', s_m1)
@@ -189,9 +191,11 @@ class SwinPlan:
         return e
 
     # ---- forward -------------------------------------------------------------------------------------------------------
-    def _record(self, B):
+    def _record(self, B, fused=True):
         """the launch sequence of one forward at batch B as a ``p2v_op`` array with its own activation buffers (built once
-        per batch size and stream slot, replayed by ``p2v_run_ops``)."""
+        per batch size and stream slot, replayed by ``p2v_run_ops``).  ``fused``: norm1 + qkv and norm2 + fc1 of stages up to 384
+        channels run as ONE launch each (``P2V_OP_LN_GEMM``: the LayerNorm output stays in LDS); the tap replay records the
+        unfused sequence, whose LayerNorm outputs exist in HBM."""
         a = self.arch
         P, g = a['patch_size'], self.g
         dev = self.device
@@ -210,6 +214,14 @@ class SwinPlan:
             o.kind, o.epi, o.inp, o.out = E.OP_GEMM, kind, E.ptr(x), E.ptr(out)
             o.M, o.K, o.N, o.lda, o.ldo = x.shape[0], x.shape[1], lin['N'], x.shape[1], lin['N']
             o.lin, o.ep = lin['lin'], epi
+            ops.append(o)
+            return out
+
+        def ln_gemm(kind, x, ln, Cc, lin, epi, out):
+            o = E.Op()
+            o.kind, o.epi, o.inp, o.out = E.OP_LN_GEMM, kind, E.ptr(x), E.ptr(out)
+            o.M, o.K, o.N, o.lda, o.ldo = x.shape[0], Cc, lin['N'], x.shape[1], lin['N']
+            o.lin, o.ep, o.ln = lin['lin'], epi, ln
             ops.append(o)
             return out
 
@@ -249,9 +261,16 @@ class SwinPlan:
             hid = buf(rows, 4 * Cc)
             for bi, b in enumerate(stg['blocks']):
                 p = 'layers.%d.blocks.%d.' % (li, bi)
-                lnorm(x, b['ln1'], Cc, ln)
-                taps.append((len(ops), p + 'qact1', ln))
-                gemm(E.EPI_REQUANT, ln, b['qkv'], epi_req(b['inv_s_qkv']), qkv)
+                e_fc1 = epi_req(b['inv_s_fc1'])
+                e_fc1.gelu = E.gelu_table(b['inv_s_fc1'], self.device)       # exact GELU -> qact1 threshold table (cached per scale)
+                fuse = (fused and b['qkv']['wf'] is not None and E.lib().p2v_ln_gemm_fusable(E.EPI_REQUANT, Cc, b['qkv']['N'], 0) == 1
+                        and E.lib().p2v_ln_gemm_fusable(E.EPI_GELU, Cc, b['fc1']['N'], e_fc1.gelu.cells if e_fc1.gelu.table else 0) == 1)
+                if fuse:
+                    ln_gemm(E.EPI_REQUANT, x, b['ln1'], Cc, b['qkv'], epi_req(b['inv_s_qkv']), qkv)
+                else:
+                    lnorm(x, b['ln1'], Cc, ln)
+                    taps.append((len(ops), p + 'qact1', ln))
+                    gemm(E.EPI_REQUANT, ln, b['qkv'], epi_req(b['inv_s_qkv']), qkv)
                 o = E.Op()
                 o.kind, o.inp, o.out = E.OP_WINATTN, E.ptr(qkv), E.ptr(att)
                 o.i0, o.i1, o.i2, o.i3 = B, T, b['heads'], 32
@@ -260,10 +279,11 @@ class SwinPlan:
                 ops.append(o)
                 gemm(E.EPI_RESID, att, b['proj'], epi_res(b['proj_epi'], x), x2)
                 taps.append((len(ops), p + 'qact2', x2))
-                lnorm(x2, b['ln2'], Cc, ln)
-                e_fc1 = epi_req(b['inv_s_fc1'])
-                e_fc1.gelu = E.gelu_table(b['inv_s_fc1'], self.device)       # exact GELU -> qact1 threshold table (cached per scale)
-                gemm(E.EPI_GELU, ln, b['fc1'], e_fc1, hid)
+                if fuse:
+                    ln_gemm(E.EPI_GELU, x2, b['ln2'], Cc, b['fc1'], e_fc1, hid)
+                else:
+                    lnorm(x2, b['ln2'], Cc, ln)
+                    gemm(E.EPI_GELU, ln, b['fc1'], e_fc1, hid)
                 gemm(E.EPI_RESID, hid, b['fc2'], epi_res(b['fc2_epi'], x2), x)
                 taps.append((len(ops), p + 'qact4', x))
             if stg['merge'] is not None:
@@ -301,9 +321,9 @@ class SwinPlan:
 
     def _replay_on_device(self, images, slot, taps, profile):
         B = images.shape[0]
-        key = (B, slot)
+        key = (B, slot, taps is None)
         if key not in self._recorded:
-            self._recorded[key] = self._record(B)
+            self._recorded[key] = self._record(B, fused=taps is None)
         r = self._recorded[key]
         out = torch.empty(B, self.head['N'], dtype=torch.float32, device=self.device)
         r['ops'][0].inp = E.ptr(images)
@@ -360,6 +380,6 @@ class SwinPlan:
         """per-op durations (ms, HIP events on the launch stream) of one single-stream forward: [(kind, epilogue, ms), ...]."""
         images = self._check_images(images)
         _, ms = self._replay(images, 0, profile=True)
-        r = self._recorded[(images.shape[0], 0)]
-        names = ('patchify', 'gemm', 'layernorm', 'window_attention', 'merge_gather', 'avgpool')
+        r = self._recorded[(images.shape[0], 0, True)]
+        names = ('patchify', 'gemm', 'layernorm', 'window_attention', 'merge_gather', 'avgpool', 'ln_gemm')
         return [(names[r['ops'][i].kind], int(r['ops'][i].epi), ms[i]) for i in range(r['n'])]

@@ -238,6 +238,9 @@ int p2v_int_layernorm(const int8_t* x, long long row_stride, int rows, int C, co
  * two calls instead. */
 int p2v_ln_gemm_i8(int epilogue_kind, const int8_t* x, long long row_stride, int M, int C, const p2v_ln* ln, int N,
                    const p2v_linear* lin, const p2v_epilogue* epi, int8_t* out, int ldo, int8_t* ln_out, void* stream);
+/* 1 when p2v_ln_gemm_i8 has an instantiation for this shape (epilogue REQUANT or GELU, C channels, N outputs, cells of the GELU table or
+ * 0) in this process (the A/B switch P2V_LN_GEMM=0 turns every shape off), else 0: callers that record launch sequences ask first. */
+int p2v_ln_gemm_fusable(int epilogue_kind, int C, int N, int gelu_table_cells);
 
 /* fused attention core on the int8 qkv tensor [batch*tokens][3*heads*head_dim] (layout of
  * qkv.reshape(B,N,3,H,hd), vit_fquant.py:309-315); out int8 [batch*tokens][heads*head_dim].
@@ -290,8 +293,10 @@ int p2v_avgpool_quant(const int8_t* x, int batch, int tokens, int C, float s_in,
  *   P2V_OP_LAYERNORM  in, out; M rows, N channels, lda / ldo row strides; ln
  *   P2V_OP_WINATTN    in (qkv), out; i0 batch, i1 tokens per image, i2 heads, i3 head_dim; wa
  *   P2V_OP_MERGE      in, out; i0 batch, i1 H, i2 W, i3 C
- *   P2V_OP_AVGPOOL    in, out; i0 batch, i1 tokens, i2 C; f0 s_in, f1 inv_s_out                                            */
-enum { P2V_OP_PATCHIFY = 0, P2V_OP_GEMM = 1, P2V_OP_LAYERNORM = 2, P2V_OP_WINATTN = 3, P2V_OP_MERGE = 4, P2V_OP_AVGPOOL = 5 };
+ *   P2V_OP_AVGPOOL    in, out; i0 batch, i1 tokens, i2 C; f0 s_in, f1 inv_s_out
+ *   P2V_OP_LN_GEMM    in (residual-stream codes), out; epi (REQUANT / GELU); M rows, K = C channels of the LayerNorm, N, lda row stride
+ *                     of `in`, ldo == N; ln; lin (w_frag required); ep      = p2v_ln_gemm_i8: LayerNorm fused into the GEMM that reads it */
+enum { P2V_OP_PATCHIFY = 0, P2V_OP_GEMM = 1, P2V_OP_LAYERNORM = 2, P2V_OP_WINATTN = 3, P2V_OP_MERGE = 4, P2V_OP_AVGPOOL = 5, P2V_OP_LN_GEMM = 6 };
 typedef struct p2v_op {
   int32_t kind, epi;
   const void* in;
