@@ -472,6 +472,77 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
   }
 }
 
+// The same epilogue for the TWO 32-row blocks a wave owns under one 32-column group (rows m_first + l31 and m_first + 32 + l31): the
+// per-channel constants depend on the columns only, so they are read from LDS once per 4-channel group and used for both blocks
+// (half the LDS reads and half the exposed read latencies of two gemm_epilogue_tile calls).  REQUANT / GELU / GELU_TAB / RESID.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_first, int n_tile, int nl, int h, const GemmArgs& g,
+                                                    const EpiLds* e, const uint4 (&resv)[2], const unsigned char* gtab = nullptr) {
+  static_assert(EPI == P2V_EPI_REQUANT || EPI == P2V_EPI_GELU || EPI == P2V_EPI_GELU_TAB || EPI == P2V_EPI_RESID, "row-pair epilogue");
+  unsigned d[2][4], res[2][4];
+  const bool row_ok[2] = {m_first < g.M, m_first + 32 < g.M};
+  if (EPI == P2V_EPI_RESID) {
+    row16_to_halves(resv[0], res[0][0], res[0][1], res[0][2], res[0][3]);
+    row16_to_halves(resv[1], res[1][0], res[1][1], res[1][2], res[1][3]);
+  }
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const int n = n_tile + 8 * gq + 4 * h, c = nl + 8 * gq + 4 * h;
+    const float4 cs = *reinterpret_cast<const float4*>(e->colscale + c);
+    const float4 bs = *reinterpret_cast<const float4*>(e->bias + c);
+    float smv[4], srv[4], snv[4], rmv[4], rnv[4], mrv[4];
+    if (EPI == P2V_EPI_RESID) {
+      const float4 sm = *reinterpret_cast<const float4*>(e->s_mid + c), sr = *reinterpret_cast<const float4*>(e->s_res + c);
+      const float4 sn = *reinterpret_cast<const float4*>(e->s_next + c), rm = *reinterpret_cast<const float4*>(e->r_mid + c);
+      const float4 rn = *reinterpret_cast<const float4*>(e->r_next + c), mr = *reinterpret_cast<const float4*>(e->m128_sres + c);
+      smv[0] = sm.x; smv[1] = sm.y; smv[2] = sm.z; smv[3] = sm.w;
+      srv[0] = sr.x; srv[1] = sr.y; srv[2] = sr.z; srv[3] = sr.w;
+      snv[0] = sn.x; snv[1] = sn.y; snv[2] = sn.z; snv[3] = sn.w;
+      rmv[0] = rm.x; rmv[1] = rm.y; rmv[2] = rm.z; rmv[3] = rm.w;
+      rnv[0] = rn.x; rnv[1] = rn.y; rnv[2] = rn.z; rnv[3] = rn.w;
+      mrv[0] = mr.x; mrv[1] = mr.y; mrv[2] = mr.z; mrv[3] = mr.w;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float y[4];
+      y[0] = __builtin_fmaf((float)acc[b][4 * gq + 0], cs.x, bs.x);      // one rounding, see gemm_epilogue_tile
+      y[1] = __builtin_fmaf((float)acc[b][4 * gq + 1], cs.y, bs.y);
+      y[2] = __builtin_fmaf((float)acc[b][4 * gq + 2], cs.z, bs.z);
+      y[3] = __builtin_fmaf((float)acc[b][4 * gq + 3], cs.w, bs.w);
+      if (EPI != P2V_EPI_RESID && g.ep.tap_out && row_ok[b] && n < g.N) {
+        const float un = EPI == P2V_EPI_REQUANT ? 1.0f / g.ep.inv_s_out : 1.0f;
+        *reinterpret_cast<float4*>(g.ep.tap_out + (long long)(m_first + 32 * b) * g.N + n) = make_float4(y[0] * un, y[1] * un, y[2] * un, y[3] * un);
+      }
+      if (EPI == P2V_EPI_GELU_TAB) {
+        d[b][gq] = gelu_tab_q8x4<false>(y, gtab, g.ep.gelu.k, g.ep.gelu.off, (float)(g.ep.gelu.cells - 1));
+        continue;
+      }
+      float q[4];
+      if (EPI == P2V_EPI_REQUANT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = rintf(y[i]);
+      } else if (EPI == P2V_EPI_GELU) {
+        gelu_q8x4(y, g.ep.inv_s_out, q);
+      } else {   // RESID, see gemm_epilogue_tile
+        float q3[4], xs[4];
+        div_q8fx4<true>(y, smv, rmv, q3);
+        const unsigned ru = res[b][gq] ^ 0x80808080u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xs[i] = __builtin_fmaf((float)((ru >> (8 * i)) & 255u), srv[i], mrv[i]) + q3[i] * smv[i];
+        div_q8fx4<false>(xs, snv, rnv, q);
+      }
+      d[b][gq] = pack4_sat(q[0], q[1], q[2], q[3]);
+    }
+    if (EPI == P2V_EPI_RESID) __builtin_amdgcn_sched_barrier(0);   // keep the constant reads of the next group from being hoisted (register pressure)
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const uint4 o = halves_to_row16(d[b][0], d[b][1], d[b][2], d[b][3]);
+    if (row_ok[b] && n_tile + 16 * h < g.N)
+      *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)(m_first + 32 * b) * g.ldo + n_tile + 16 * h) = o;
+  }
+}
+
 // one k-tile of MFMA work for a wave: 2 k-steps x (1 weight frag, 2 activation frags, 2 MFMAs)
 template <bool W4>
 __device__ __forceinline__ void gemm_compute_tile(const int8_t* cx, const int8_t* cw, int wm, int wn, int l31, int h, v16i (&acc)[2]) {
@@ -883,10 +954,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 4 : 3) void k_gemm_dma(GemmArgs g) 
   __syncthreads();        // nothing is in flight any more; orders the constant stores before the epilogue reads for every wave
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-      gemm_epilogue_tile<EPI>(acc[ni][mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, sE,
-                              EPI == P2V_EPI_RESID ? resv[ni][mi] : make_uint4(0, 0, 0, 0), dyn_lds);
+    gemm_epilogue_tile2<EPI>(acc[ni], m0 + wm * 64 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, sE, resv[ni], dyn_lds);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1295,11 +1363,13 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
     }
     LG_STAMP(4 + 2 * j);
     const EpiLds* e = reinterpret_cast<const EpiLds*>(consts + j * 2 * GBN);
+    {
+      const uint4 nores[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+      gemm_epilogue_tile2<EPI>(acc, m0 + l31, j * GBN + 32 * wave, 32 * wave, h, g, e, nores, gtab);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      gemm_epilogue_tile<EPI>(acc[mi], m0 + mi * 32 + l31, j * GBN + 32 * wave, 32 * wave, h, g, e, make_uint4(0, 0, 0, 0), gtab);
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][r] = 0;
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0;
     }
     LG_STAMP(5 + 2 * j);
   }
