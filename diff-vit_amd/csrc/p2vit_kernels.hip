@@ -485,22 +485,35 @@ __device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_
     row16_to_halves(resv[0], res[0][0], res[0][1], res[0][2], res[0][3]);
     row16_to_halves(resv[1], res[1][0], res[1][1], res[1][2], res[1][3]);
   }
+  // the constants of group gq + 1 are requested before group gq is computed (their LDS latency hides behind ~130 VALU instructions)
+  struct Consts { float4 cs, bs, sm, sr, sn, rm, rn, mr; };
+  auto load_consts = [&](int gq) {
+    const int c = nl + 8 * gq + 4 * h;
+    Consts k;
+    k.cs = *reinterpret_cast<const float4*>(e->colscale + c);
+    k.bs = *reinterpret_cast<const float4*>(e->bias + c);
+    if (EPI == P2V_EPI_RESID) {
+      k.sm = *reinterpret_cast<const float4*>(e->s_mid + c); k.sr = *reinterpret_cast<const float4*>(e->s_res + c);
+      k.sn = *reinterpret_cast<const float4*>(e->s_next + c); k.rm = *reinterpret_cast<const float4*>(e->r_mid + c);
+      k.rn = *reinterpret_cast<const float4*>(e->r_next + c); k.mr = *reinterpret_cast<const float4*>(e->m128_sres + c);
+    }
+    return k;
+  };
+  Consts knext = load_consts(0);
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
-    const int n = n_tile + 8 * gq + 4 * h, c = nl + 8 * gq + 4 * h;
-    const float4 cs = *reinterpret_cast<const float4*>(e->colscale + c);
-    const float4 bs = *reinterpret_cast<const float4*>(e->bias + c);
+    const int n = n_tile + 8 * gq + 4 * h;
+    const Consts k = knext;
+    if (gq < 3) knext = load_consts(gq + 1);
+    const float4 cs = k.cs, bs = k.bs;
     float smv[4], srv[4], snv[4], rmv[4], rnv[4], mrv[4];
     if (EPI == P2V_EPI_RESID) {
-      const float4 sm = *reinterpret_cast<const float4*>(e->s_mid + c), sr = *reinterpret_cast<const float4*>(e->s_res + c);
-      const float4 sn = *reinterpret_cast<const float4*>(e->s_next + c), rm = *reinterpret_cast<const float4*>(e->r_mid + c);
-      const float4 rn = *reinterpret_cast<const float4*>(e->r_next + c), mr = *reinterpret_cast<const float4*>(e->m128_sres + c);
-      smv[0] = sm.x; smv[1] = sm.y; smv[2] = sm.z; smv[3] = sm.w;
-      srv[0] = sr.x; srv[1] = sr.y; srv[2] = sr.z; srv[3] = sr.w;
-      snv[0] = sn.x; snv[1] = sn.y; snv[2] = sn.z; snv[3] = sn.w;
-      rmv[0] = rm.x; rmv[1] = rm.y; rmv[2] = rm.z; rmv[3] = rm.w;
-      rnv[0] = rn.x; rnv[1] = rn.y; rnv[2] = rn.z; rnv[3] = rn.w;
-      mrv[0] = mr.x; mrv[1] = mr.y; mrv[2] = mr.z; mrv[3] = mr.w;
+      smv[0] = k.sm.x; smv[1] = k.sm.y; smv[2] = k.sm.z; smv[3] = k.sm.w;
+      srv[0] = k.sr.x; srv[1] = k.sr.y; srv[2] = k.sr.z; srv[3] = k.sr.w;
+      snv[0] = k.sn.x; snv[1] = k.sn.y; snv[2] = k.sn.z; snv[3] = k.sn.w;
+      rmv[0] = k.rm.x; rmv[1] = k.rm.y; rmv[2] = k.rm.z; rmv[3] = k.rm.w;
+      rnv[0] = k.rn.x; rnv[1] = k.rn.y; rnv[2] = k.rn.z; rnv[3] = k.rn.w;
+      mrv[0] = k.mr.x; mrv[1] = k.mr.y; mrv[2] = k.mr.z; mrv[3] = k.mr.w;
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
