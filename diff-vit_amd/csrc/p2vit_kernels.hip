@@ -193,6 +193,26 @@ __device__ __forceinline__ unsigned gelu_tab_q8x4(const float (&y)[4], const uns
   return d;
 }
 
+// two groups of four at once: all eight table reads are requested before the first select waits for one
+__device__ __forceinline__ void gelu_tab_q8x8(const float (&y0)[4], const float (&y1)[4], const unsigned char* tab, float k, float off, float tmax,
+                                              unsigned& d0, unsigned& d1) {
+  uint2 e0[4], e1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e0[i] = *reinterpret_cast<const uint2*>(tab + gelu_tab_offset(y0[i], k, off, tmax));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e1[i] = *reinterpret_cast<const uint2*>(tab + gelu_tab_offset(y1[i], k, off, tmax));
+  d0 = 0;
+  d1 = 0;
+  P2V_GELU_SEL(0, "UNUSED_PAD", d0, y0[0], e0[0]);
+  P2V_GELU_SEL(1, "UNUSED_PRESERVE", d0, y0[1], e0[1]);
+  P2V_GELU_SEL(2, "UNUSED_PRESERVE", d0, y0[2], e0[2]);
+  P2V_GELU_SEL(3, "UNUSED_PRESERVE", d0, y0[3], e0[3]);
+  P2V_GELU_SEL(0, "UNUSED_PAD", d1, y1[0], e1[0]);
+  P2V_GELU_SEL(1, "UNUSED_PRESERVE", d1, y1[1], e1[1]);
+  P2V_GELU_SEL(2, "UNUSED_PRESERVE", d1, y1[2], e1[2]);
+  P2V_GELU_SEL(3, "UNUSED_PRESERVE", d1, y1[3], e1[3]);
+}
+
 // n-th finite fp32 in real-line order: n in [0, 2F), F = 0x7F800000 (negative values by falling magnitude, -0, +0, positives)
 #define P2V_F32_FINITE 0x7F800000ull
 __device__ __forceinline__ float f32_in_order(unsigned long long n) {
@@ -515,21 +535,26 @@ __device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_
       rnv[0] = k.rn.x; rnv[1] = k.rn.y; rnv[2] = k.rn.z; rnv[3] = k.rn.w;
       mrv[0] = k.mr.x; mrv[1] = k.mr.y; mrv[2] = k.mr.z; mrv[3] = k.mr.w;
     }
+    float yy[2][4];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      float y[4];
-      y[0] = __builtin_fmaf((float)acc[b][4 * gq + 0], cs.x, bs.x);      // one rounding, see gemm_epilogue_tile
-      y[1] = __builtin_fmaf((float)acc[b][4 * gq + 1], cs.y, bs.y);
-      y[2] = __builtin_fmaf((float)acc[b][4 * gq + 2], cs.z, bs.z);
-      y[3] = __builtin_fmaf((float)acc[b][4 * gq + 3], cs.w, bs.w);
+      yy[b][0] = __builtin_fmaf((float)acc[b][4 * gq + 0], cs.x, bs.x);      // one rounding, see gemm_epilogue_tile
+      yy[b][1] = __builtin_fmaf((float)acc[b][4 * gq + 1], cs.y, bs.y);
+      yy[b][2] = __builtin_fmaf((float)acc[b][4 * gq + 2], cs.z, bs.z);
+      yy[b][3] = __builtin_fmaf((float)acc[b][4 * gq + 3], cs.w, bs.w);
       if (EPI != P2V_EPI_RESID && g.ep.tap_out && row_ok[b] && n < g.N) {
         const float un = EPI == P2V_EPI_REQUANT ? 1.0f / g.ep.inv_s_out : 1.0f;
-        *reinterpret_cast<float4*>(g.ep.tap_out + (long long)(m_first + 32 * b) * g.N + n) = make_float4(y[0] * un, y[1] * un, y[2] * un, y[3] * un);
+        *reinterpret_cast<float4*>(g.ep.tap_out + (long long)(m_first + 32 * b) * g.N + n) =
+            make_float4(yy[b][0] * un, yy[b][1] * un, yy[b][2] * un, yy[b][3] * un);
       }
-      if (EPI == P2V_EPI_GELU_TAB) {
-        d[b][gq] = gelu_tab_q8x4<false>(y, gtab, g.ep.gelu.k, g.ep.gelu.off, (float)(g.ep.gelu.cells - 1));
-        continue;
-      }
+    }
+    if (EPI == P2V_EPI_GELU_TAB) {
+      gelu_tab_q8x8(yy[0], yy[1], gtab, g.ep.gelu.k, g.ep.gelu.off, (float)(g.ep.gelu.cells - 1), d[0][gq], d[1][gq]);
+      continue;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float (&y)[4] = yy[b];
       float q[4];
       if (EPI == P2V_EPI_REQUANT) {
 #pragma unroll
