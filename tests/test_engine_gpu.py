@@ -374,10 +374,21 @@ def test_ln_gemm_fused_vs_separate_and_oracle(dva, oracle, C_, N, M, kind, table
     E.check(L.p2v_ln_gemm_i8(ek, E.ptr(d[0]), C_, M, C_, C.byref(lnp), N, C.byref(lin), C.byref(epi), E.ptr(out_f), N, E.ptr(ln_f), E.stream_ptr()))
     out_g = torch.full((M, N), 55, dtype=torch.int8, device='cuda')          # without the optional LayerNorm output
     E.check(L.p2v_ln_gemm_i8(ek, E.ptr(d[0]), C_, M, C_, C.byref(lnp), N, C.byref(lin), C.byref(epi), E.ptr(out_g), N, None, E.stream_ptr()))
+    # the same launch as a recorded op (P2V_OP_LN_GEMM through p2v_run_ops: the Swin plan's route), after asking p2v_ln_gemm_fusable
+    cells = epi.gelu.cells if (table and epi.gelu.table) else 0
+    assert L.p2v_ln_gemm_fusable(ek, C_, N, cells) == 1
+    assert L.p2v_ln_gemm_fusable(ek, 1024, N, cells) == 0 and L.p2v_ln_gemm_fusable(E.EPI_RESID, C_, N, 0) == 0
+    out_o = torch.full((M, N), 33, dtype=torch.int8, device='cuda')
+    o = E.Op()
+    o.kind, o.epi, o.inp, o.out = E.OP_LN_GEMM, ek, E.ptr(d[0]), E.ptr(out_o)
+    o.M, o.K, o.N, o.lda, o.ldo = M, C_, N, C_, N
+    o.lin, o.ep, o.ln = lin, epi, lnp
+    E.check(L.p2v_run_ops((E.Op * 1)(o), 1, E.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(ln_f, ln_sep[:, :C_])
     assert torch.equal(out_f, out_sep), int((out_f != out_sep).sum())
     assert torch.equal(out_g, out_sep)
+    assert torch.equal(out_o, out_sep)
     if pot:
         ln = oracle.int_layernorm(codes * in_scale.reshape(1, 1, -1), in_scale, gamma, beta, out_scale)
         q0 = torch.clamp(torch.round((ln * out_scale.reshape(1, 1, -1)) / cs.reshape(1, 1, -1) / s_a), -128, 127)[0]
