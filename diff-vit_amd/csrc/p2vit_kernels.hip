@@ -2040,8 +2040,14 @@ bool p2v_ln_gemm_supported(int epi, int C, int N, int table_cells) {
 template <int EPI, int KT>
 static int launch_ln_gemm_t(const LnArgs& a, const GemmArgs& g, int cells, hipStream_t st) {
   const int smem = ln_gemm_lds(a.C, g.N, (KT + 1) / 2, cells).total;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_gemm<EPI, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  if (e != hipSuccess) return (int)e;
+  static int granted[16] = {0};                 // per device: the dynamic LDS size this instantiation has been allowed so far
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+  if (dev < 0 || smem > granted[dev]) {         // (a racing second thread only repeats the call)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_gemm<EPI, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 0) granted[dev] = smem;
+  }
   hipLaunchKernelGGL((k_ln_gemm<EPI, KT>), dim3((unsigned)((g.M + LG_BM - 1) / LG_BM)), dim3(256), (unsigned)smem, st, a, g);
   CHECK_LAUNCH();
   return 0;
