@@ -1261,8 +1261,8 @@ __host__ __device__ inline LnGemmLds ln_gemm_lds(int K, int N, int nch, int tabl
   const int kt = (K + GBK - 1) / GBK, tiles_n = (N + GBN - 1) / GBN;
   o.panel = 0;
   o.consts = o.panel + kt * LG_BM * GBK;
-  o.fold = o.consts + tiles_n * GBN * 2 * (int)sizeof(float);
-  o.table = o.fold + 4 * nch * 128 * (int)sizeof(float);
+  o.fold = o.panel;        // the LayerNorm fold scratch (4 * nch * 512 B <= the panel) is dead before the first panel row is written
+  o.table = o.consts + tiles_n * GBN * 2 * (int)sizeof(float);
   o.total = o.table + table_cells * 8;
   return o;
 }
@@ -1338,6 +1338,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
     int* sM = reinterpret_cast<int*>(sP + NCH * 128);
     LnLane<NCH> L;
     ln_prepare<NCH, 32>(a.ln, C, a.force_generic != 0, sG, sB, sP, sM, tid, 256, L);
+    __syncthreads();        // every lane holds its folded constants in registers: the scratch (= the panel) may be overwritten
 #pragma unroll 1
     for (int r = 0; r < RPH; r += 2) {
       unsigned wnext[2][NCH];
