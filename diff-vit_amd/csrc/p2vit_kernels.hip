@@ -1014,14 +1014,17 @@ __device__ __forceinline__ int half_wave_sum(int v) {
 }
 
 // generic per-element chain: every step of get_MN / the 'int' forward as written in the reference
-__device__ __forceinline__ float ln_elem_generic(float xq, float g, float bta, float io, float pm, float rs, float mos) {
-  const float A = (rs * g) * io;                                   // (s1/std)*gamma / out_scale
+// os > 0: the output scale itself - the two quotients are IEEE divisions like the reference's; os == 0: multiply by io = 1/scale
+// (identical for powers of two)
+__device__ __forceinline__ float ln_elem_generic(float xq, float g, float bta, float io, float pm, float rs, float mos, float os) {
+  const float A = os > 0.f ? (rs * g) / os : (rs * g) * io;        // (s1/std)*gamma / out_scale
   const float absA = fabsf(A);
   int N = 134 - (int)(__float_as_uint(absA) >> 23);                // 7 - floor(log2|A|)   (get_MN, layers.py:234-238)
   N = N < 0 ? 0 : (N > 31 ? 31 : N);
   const float M = fminf(floorf(ldexpf(absA, N)), 255.f);           // floor(|A| * 2^N), clamped
   const float sM = copysignf(M, A);                                // A.sign() * M  (M == 0 when A == 0)
-  const float Bv = rintf(ldexpf((bta - mos * g) * io, N));         // layers.py:283-286
+  const float tb = bta - mos * g;
+  const float Bv = rintf(ldexpf(os > 0.f ? tb / os : tb * io, N)); // layers.py:283-286
   const float o = rintf(ldexpf(sM * xq + Bv, -N));                 // layers.py:288
   return rintf(o * pm);                                            // * out_scale / cs_next / s_next (clamped by the packing)
 }
@@ -1182,9 +1185,12 @@ __device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane
       const float4 iv = *reinterpret_cast<const float4*>(ln.inv_out + cc), pv = *reinterpret_cast<const float4*>(ln.post_mul + cc);
       const float g4[4] = {gv.x, gv.y, gv.z, gv.w}, b4[4] = {bv.x, bv.y, bv.z, bv.w};
       const float i4[4] = {iv.x, iv.y, iv.z, iv.w}, p4[4] = {pv.x, pv.y, pv.z, pv.w};
+      float4 ov = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ln.out_scale) ov = *reinterpret_cast<const float4*>(ln.out_scale + cc);
+      const float o4[4] = {ov.x, ov.y, ov.z, ov.w};
       float q[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q[j] = ln_elem_generic(xq[i][j], g4[j], b4[j], i4[j], p4[j], rs, mos);
+      for (int j = 0; j < 4; ++j) q[j] = ln_elem_generic(xq[i][j], g4[j], b4[j], i4[j], p4[j], rs, mos, o4[j]);
       outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
     }
   }

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libp2vit_hip.so')
 
-P2V_ABI_VERSION = 2
+P2V_ABI_VERSION = 3
 EPI_REQUANT, EPI_GELU, EPI_RESID, EPI_EMBED, EPI_HEAD = 0, 1, 2, 3, 4
 E_ARG, E_BITS, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH, E_STATE = -1, -2, -3, -4, -5, -6, -7
 
@@ -30,7 +30,7 @@ class Linear(C.Structure):
 
 
 class Ln(C.Structure):
-    _fields_ = [('s1', _f), ('mask', _p), ('gamma', _p), ('beta', _p), ('inv_out', _p), ('post_mul', _p)]
+    _fields_ = [('s1', _f), ('mask', _p), ('gamma', _p), ('beta', _p), ('inv_out', _p), ('post_mul', _p), ('out_scale', _p)]
 
 
 class Attn(C.Structure):

@@ -23,8 +23,8 @@
  *   - ViT attention: head_dim 32 or 64; tokens per image <= 64 or 193..224 (i.e. 224^2 / 16 and the test geometries; 384^2 is not
  *     built); Swin window attention: head_dim 32, windows up to 8 x 8;
  *   - LayerNorm: up to 2048 channels, PTF input masks (in_scale / min in_scale) in {1, 2, 4, 8};
- *   - p2v_ln.inv_out is MULTIPLIED by (the reference divides by the scale): identical for the power-of-two scales of this path; for any
- *     other value the 8-bit multiplier M can land one step away on about 1e-5 of the elements;
+ *   - LayerNorm output scale: p2v_ln.inv_out is MULTIPLIED by where the reference divides by the scale - identical for the power-of-two
+ *     scales of this path; for any other scale pass p2v_ln.out_scale too and the kernel divides (exact, ABI 3);
  *   - REQUANT epilogues fold 1/scale into the column constants: it must be a power of two;
  *   - log-int-softmax constants: c_int < 2^24 (qact_attn1 scale >= 2^-11).
  */
@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define P2V_ABI_VERSION 2
+#define P2V_ABI_VERSION 3
 
 enum {
   P2V_OK = 0,
@@ -94,17 +94,20 @@ typedef struct p2v_linear {
  * channel scale and the QAct that follows it (vit_fquant.py:284-289, layers_quant.py:305-311).
  *   x_q = code * mask[c];  mask[c] = round(in_scale[c] / s1), s1 = min_c in_scale[c]
  *   out = clamp(rne(LN_int(x_q) * post_mul[c]), -128, 127)
- * inv_out[c] = 1 / (out_quantizer.scale * out_quantizer_scale[c])  (power of two: the kernel multiplies by it where the
- *              reference divides by the scale, which is the same fp32 value only for powers of two; with any other value the
- *              8-bit multiplier M can land one step away when A sits on a dyadic boundary - about 1e-5 of the elements)
+ * inv_out[c] = 1 / (out_quantizer.scale * out_quantizer_scale[c])  (a power of two in P2-ViT: multiplying by it IS the reference's
+ *              division by the scale)
+ * out_scale[c] = the scale itself, optional (NULL): needed only when it is NOT a power of two - the kernel then divides by it
+ *              (IEEE) exactly where the reference does (layers.py:279-286); with NULL it multiplies by inv_out, which for such a
+ *              scale lands the 8-bit multiplier M one step away on about 1e-5 of the elements
  * post_mul[c] = out_scale[c] / next_channel_scale[c] / next_act_scale  (power of two). */
 typedef struct p2v_ln {
   float s1;
-  const float* mask;     /* dev [C] */
-  const float* gamma;    /* dev [C] */
-  const float* beta;     /* dev [C] */
-  const float* inv_out;  /* dev [C] */
-  const float* post_mul; /* dev [C] */
+  const float* mask;      /* dev [C] */
+  const float* gamma;     /* dev [C] */
+  const float* beta;      /* dev [C] */
+  const float* inv_out;   /* dev [C] */
+  const float* post_mul;  /* dev [C] */
+  const float* out_scale; /* dev [C] or NULL (ABI 3) */
 } p2v_ln;
 
 /* (q @ k^T) * scale -> qact_attn1 -> QIntSoftmax (log-int-softmax, uint4) -> @ v -> qact2

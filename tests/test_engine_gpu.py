@@ -935,8 +935,9 @@ def test_fuzz_ops_against_oracle():
 
 def test_int_layernorm_kernel_vs_randomised_reference_vectors(dva):
     """HIP LayerNorm directly against the REAL reference's QIntLayerNorm outputs (tests/golden/kat_fuzz.npz): zero / tiny / huge gamma,
-    PTF input scales, in_scale_expand 4.  Rows the reference turns into NaN/inf (zero variance) are skipped; the cases with a non
-    power-of-two output scale may differ on one element (include/p2vit.h: the ABI multiplies by 1/scale)."""
+    PTF input scales, in_scale_expand 4.  Rows the reference turns into NaN/inf (zero variance) are skipped.  With p2v_ln.out_scale set
+    the kernel divides where the reference divides: every case is exact, power-of-two output scale or not; without it (multiplication
+    by 1/scale, exact for powers of two) a non power-of-two case may differ on one element."""
     E = dva.engine
     g = load_golden('kat_fuzz')
     for i in range(int(g['ln/n'])):
@@ -954,13 +955,15 @@ def test_int_layernorm_kernel_vs_randomised_reference_vectors(dva):
         s1 = s_in.min()
         dev = [t.contiguous().cuda() for t in (codes, torch.round(s_in / s1), torch.from_numpy(g[p + 'gamma']), torch.from_numpy(g[p + 'beta']),
                                                1.0 / out_scale, torch.ones(C_))]
-        lnp = E.Ln(float(s1), *[E.ptr(t) for t in dev[1:]])
-        out = torch.zeros(rows, C_, dtype=torch.int8, device='cuda')
-        E.check(E.lib().p2v_int_layernorm(E.ptr(dev[0]), C_, rows, C_, C.byref(lnp), E.ptr(out), C_, E.stream_ptr()))
-        got = out.cpu().float()
-        bad = int((got[finite] != want[finite]).sum())
         pot = bool((torch.frexp(out_scale)[0] == 0.5).all())
-        assert bad == 0 or (not pot and bad <= 1), (i, bad, pot)
+        os_dev = out_scale.contiguous().cuda()
+        for with_scale in (True, False):
+            lnp = E.Ln(float(s1), *([E.ptr(t) for t in dev[1:]] + ([E.ptr(os_dev)] if with_scale else [])))
+            out = torch.zeros(rows, C_, dtype=torch.int8, device='cuda')
+            E.check(E.lib().p2v_int_layernorm(E.ptr(dev[0]), C_, rows, C_, C.byref(lnp), E.ptr(out), C_, E.stream_ptr()))
+            got = out.cpu().float()
+            bad = int((got[finite] != want[finite]).sum())
+            assert bad == 0 or (not with_scale and not pot and bad <= 1), (i, bad, pot, with_scale)
 
 
 def test_bench_two_ranks_on_one_gpu_gloo(dva):
