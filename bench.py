@@ -60,7 +60,7 @@ def bench_swin(args, dva, dev, world, rank):
     model.load_state_dict(dva.synth.swin_state_dict(model.state_dict(), SEED))
     model = model.to(dev).eval()
     arch = model.arch
-    base = dva.synth.images(1000 + rank, min(args.batch, 32), arch['img_size'])
+    base = dva.synth.images(1000 + rank, args.batch, arch['img_size'])
     with torch.no_grad():
         fp32_top1 = model(base.to(dev)).argmax(1).cpu()
         t_cal = time.perf_counter()
@@ -200,7 +200,7 @@ def main():
         model = dva.harness.str2model(args.model)(cfg=dva.Config(True, True, 'minmax'))
     model.load_state_dict(sd, strict=False)
     model = model.to(dev).eval()
-    base = dva.synth.images(1000 + rank, min(args.batch, 32), arch['img_size'])
+    base = dva.synth.images(1000 + rank, args.batch, arch['img_size'])
     with torch.no_grad():                                 # fp32 teacher on the distinct images, before any calibration
         fp32_top1 = model(base.to(dev))[0].argmax(1).cpu()
     t_cal = time.perf_counter()
@@ -217,7 +217,7 @@ def main():
     n_elems = sum(ref_calib[k].numel() for k in ref_calib)
     plan = model.freeze(dev)
     B = args.batch
-    # 32 distinct synthetic images per rank, tiled to the batch (content does not change the work)
+    # every image of the batch is distinct (counter-based generator, seed 1000 + rank)
     x = base.repeat((B + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
     bits = [args.bits] * (4 * arch['depth'] + 2)
     logits = torch.empty(B, arch['num_classes'], device=dev)
@@ -243,7 +243,7 @@ def main():
             gather_ok = True
             chk = torch.empty_like(logits)
             for r in range(world):
-                br = dva.synth.images(1000 + r, min(args.batch, 32), arch['img_size'])
+                br = dva.synth.images(1000 + r, args.batch, arch['img_size'])
                 xr = br.repeat((B + br.shape[0] - 1) // br.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
                 plan.forward_streams(xr, bits, chk, args.streams)
                 gather_ok = gather_ok and bool(torch.equal(chk, out[0][r * B:(r + 1) * B]))
