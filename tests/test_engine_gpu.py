@@ -399,13 +399,15 @@ def test_ln_gemm_fused_vs_separate_and_oracle(dva, oracle, C_, N, M, kind, table
         assert torch.equal(out_f.cpu().float(), ref), int((out_f.cpu().float() != ref).sum())
 
 
-@pytest.mark.parametrize('B,N,H,hd,e_at', [(2, 17, 2, 32, 4), (3, 49, 4, 32, 5), (2, 197, 3, 64, 4), (1, 197, 6, 64, 6), (2, 50, 2, 64, 3)])
+@pytest.mark.parametrize('B,N,H,hd,e_at', [(2, 17, 2, 32, 4), (3, 49, 4, 32, 5), (2, 197, 3, 64, 4), (1, 197, 6, 64, 6), (2, 50, 2, 64, 3),
+                                          (1, 193, 2, 64, 5), (1, 224, 2, 64, 4), (1, 209, 1, 32, 4), (1, 64, 2, 64, 4), (1, 1, 1, 32, 4)])
 def test_lis_attention(dva, oracle, B, N, H, hd, e_at):
     E, S = dva.engine, dva.synth
     D = H * hd
     qkv = _rand_codes(S, 4, 'aq%d' % N, (B, N, 3 * D), 30.0)
     qkv[0, 0, :D] = 127                      # a saturating score row
-    qkv[0, 1, :D] = 0                        # an all-equal score row
+    if N > 1:
+        qkv[0, 1, :D] = 0                    # an all-equal score row
     s_q1, s_at, s_a2 = 2.0 ** -4, 2.0 ** -e_at, 2.0 ** -3
     t = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
     acc = t[0] @ t[1].transpose(-2, -1)
