@@ -199,7 +199,7 @@ def _rand_codes(synth, seed, name, shape, std=40.0):
     return torch.clamp(torch.round(synth.normal(seed, name, shape, std)), -128, 127)
 
 
-@pytest.mark.parametrize('M,K,N', [(300, 64, 192), (394, 384, 1152), (130, 1536, 384)])
+@pytest.mark.parametrize('M,K,N', [(300, 64, 192), (394, 384, 1152), (130, 1536, 384), (1, 64, 128), (257, 128, 400), (128, 192, 16)])
 def test_gemm_requant_and_gelu(dva, oracle, M, K, N):
     E, S = dva.engine, dva.synth
     x = _rand_codes(S, 1, 'gx', (M, K))
@@ -227,7 +227,7 @@ def test_gemm_requant_and_gelu(dva, oracle, M, K, N):
         ref = torch.clamp(torch.round(v / s_out), -128, 127)
         got = out.cpu().float()
         assert torch.equal(got, ref), (kind, int((got != ref).sum()))
-        assert ref.abs().max() == 128 or ref.max() == 127          # clamps exercised
+        assert M * N < 30000 or ref.abs().max() == 128 or ref.max() == 127          # clamps exercised
 
 
 @pytest.mark.parametrize('M,K,N', [(300, 64, 192), (394, 384, 1152), (130, 1536, 384), (77, 768, 1000)])
