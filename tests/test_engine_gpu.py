@@ -926,8 +926,9 @@ def test_swin_batch_independence_and_stream_slices(dva):
 
 def test_fuzz_ops_against_oracle():
     """tools/fuzz_ops.py: random odd shapes and extreme parameters (zero / tiny / huge gamma, non power-of-two LN output scales,
-    zero-variance rows, all-equal score rows, PTF scales, shifted-window masks, ...) for LayerNorm, ViT attention, Swin window attention and
-    the three GEMM epilogues."""
+    zero-variance rows, all-equal score rows, PTF scales, shifted-window masks, ...) for LayerNorm (with and without the exact
+    p2v_ln.out_scale division), ViT attention, Swin window attention, the three GEMM epilogues and the fused LayerNorm+GEMM against its
+    two separate calls."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_ops.py'), '3', '12'], capture_output=True, text=True, timeout=600)

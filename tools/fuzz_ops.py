@@ -38,13 +38,14 @@ def ln_case(i):
     ref = torch.nan_to_num(ref, nan=0.0)
     s1 = in_scale.min()
     dev = [t.contiguous().cuda() for t in (codes[0].to(torch.int8), torch.round(in_scale / s1), gamma, beta, 1.0 / out_scale, torch.ones(C_))]
-    lnp = E.Ln(float(s1), *[E.ptr(t) for t in dev[1:]])
+    os_dev = out_scale.contiguous().cuda()
+    lnp = E.Ln(float(s1), *([E.ptr(t) for t in dev[1:]] + ([E.ptr(os_dev)] if i % 2 else [])))     # odd cases: exact division by the scale
     out = torch.zeros(rows, C_, dtype=torch.int8, device='cuda')
     E.check(L.p2v_int_layernorm(E.ptr(dev[0]), C_, rows, C_, C.byref(lnp), E.ptr(out), C_, E.stream_ptr()))
     got = out.cpu().float()
     finite = torch.isfinite(ln[0]).all(dim=1)            # rows with std == 0 give inf/nan in the reference: not compared
     bad = int((got[finite] != ref[finite]).sum())
-    if bad and i % 7 == 0:
+    if bad and i % 7 == 0 and i % 2 == 0:
         # non power-of-two output scale: the ABI takes 1/out_scale and multiplies where the reference divides (exact only for
         # powers of two, the P2-ViT case; include/p2vit.h): a multiplier on a dyadic boundary may land one step away
         if bad <= max(1, int(1e-4 * got[finite].numel())):       # one 8-bit multiplier off by one step: |diff| <= |x_q| / 2^N + 1
@@ -62,6 +63,56 @@ def ln_case(i):
             print('   row %d col %d got %g want %g | ln %.6f gamma %.6g beta %.6g out_scale %.6g A %.6g code %g mask %g' %
                   (r_, c_, float(got[r_, c_]), float(ref[r_, c_]), float(ln[0, r_, c_]), float(gamma[c_]), float(beta[c_]), float(out_scale[c_]),
                    float(A), float(codes[0, r_, c_]), float(torch.round(in_scale / s1)[c_])))
+
+
+
+def ln_gemm_case(i):
+    """p2v_ln_gemm_i8 against p2v_int_layernorm + p2v_gemm_i8 (bit-identical by contract) over random widths, rows and epilogues."""
+    global fails
+    C_ = int(torch.randint(1, 97, (1,), generator=g)) * 4                      # 4 .. 384
+    N = int(torch.randint(1, 97, (1,), generator=g)) * 16                      # 16 .. 1536
+    M = int(torch.randint(1, 400, (1,), generator=g))
+    kind = E.EPI_GELU if i % 2 else E.EPI_REQUANT
+    codes = torch.clamp(torch.round(rnd(M, C_, std=float(torch.rand(1, generator=g)) * 60 + 1)), -128, 127)
+    in_scale = float(2.0 ** torch.randint(-9, 0, (1,), generator=g)) * 2.0 ** torch.randint(0, 4, (C_,), generator=g).float()
+    gamma = rnd(C_, std=1.0); beta = rnd(C_, std=0.5)
+    if i % 4 == 1:
+        gamma[::5] = 0.0
+    cs = 2.0 ** torch.randint(-2, 3, (C_,), generator=g).float()
+    s_a = float(2.0 ** torch.randint(-6, -2, (1,), generator=g))
+    out_scale = s_a * cs * (1.0 if i % 5 else 1.3)                             # sometimes the generic LayerNorm chain
+    post = out_scale / cs / s_a if i % 5 else torch.ones(C_)
+    s1 = in_scale.min()
+    k_pad, n_pad = (C_ + 63) // 64 * 64, (N + 127) // 128 * 128
+    wp = torch.zeros(n_pad, k_pad, dtype=torch.int8)
+    wp[:N, :C_] = torch.clamp(torch.round(rnd(N, C_, std=30.0)), -128, 127).to(torch.int8)
+    csl = torch.zeros(n_pad); csl[:N] = s_a * 2.0 ** torch.randint(-8, -5, (N,), generator=g).float()
+    bp = torch.zeros(n_pad); bp[:N] = rnd(N, std=0.4)
+    d = [t.contiguous().cuda() for t in (codes.to(torch.int8), torch.round(in_scale / s1), gamma, beta, 1.0 / out_scale, post, wp, csl, bp)]
+    lnp = E.Ln(float(s1), *[E.ptr(t) for t in d[1:6]])
+    wfrag = E.fragment_order(wp).cuda()
+    lin = E.Linear(E.ptr(d[6]), E.ptr(d[7]), E.ptr(d[8]), E.ptr(wfrag))
+    epi = E.Epilogue()
+    inv_s = float(2.0 ** torch.randint(3, 6, (1,), generator=g))
+    epi.inv_s_out = inv_s
+    if kind == E.EPI_GELU and i % 4 != 3:
+        epi.gelu = E.gelu_table(inv_s, 'cuda')
+    cells = epi.gelu.cells if epi.gelu.table else 0
+    if L.p2v_ln_gemm_fusable(kind, C_, N, cells) != 1:
+        return
+    ln_sep = torch.zeros(M, k_pad, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_int_layernorm(E.ptr(d[0]), C_, M, C_, C.byref(lnp), E.ptr(ln_sep), k_pad, E.stream_ptr()))
+    out_sep = torch.zeros(M, N, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_gemm_i8(kind, E.ptr(ln_sep), k_pad, M, k_pad, N, C.byref(lin), C.byref(epi), E.ptr(out_sep), N, None, E.stream_ptr()))
+    out_f = torch.full((M, N), 77, dtype=torch.int8, device='cuda')
+    ln_f = torch.full((M, C_), 99, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_ln_gemm_i8(kind, E.ptr(d[0]), C_, M, C_, C.byref(lnp), N, C.byref(lin), C.byref(epi), E.ptr(out_f), N, E.ptr(ln_f), E.stream_ptr()))
+    torch.cuda.synchronize()
+    finite = torch.isfinite(O.int_layernorm(codes.unsqueeze(0) * in_scale.reshape(1, 1, -1), in_scale, gamma, beta, out_scale)[0]).all(dim=1).cuda()
+    bad = int((out_f[finite] != out_sep[finite]).sum()) + int((ln_f[finite] != ln_sep[finite][:, :C_]).sum())
+    if bad:
+        fails += 1
+        print('LN+GEMM case %d C=%d N=%d M=%d kind=%d: %d mismatches' % (i, C_, N, M, kind, bad))
 
 
 def attn_case(i):
@@ -201,6 +252,7 @@ for i in range(n):
     attn_case(i)
     gemm_case(i)
     winattn_case(i)
+    ln_gemm_case(i)
 torch.cuda.synchronize()
 print('fuzz: %d cases per op, %d failing' % (n, fails))
 sys.exit(1 if fails else 0)
