@@ -178,6 +178,8 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         sys.exit('bench.py --gpus %d was started with WORLD_SIZE=%d' % (args.gpus, world))
+    if world > 1:      # the one-off host calibration of every rank runs at the same time: share the host cores instead of oversubscribing them
+        torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // world)))
     import diff_vit_amd as dva
     from diff_vit_amd import calib_io
     local = local % max(1, torch.cuda.device_count())
