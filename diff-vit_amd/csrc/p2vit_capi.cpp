@@ -70,7 +70,7 @@ static void read_env_once() {
   const char* e = getenv("P2V_ATTN_WAVES");
   if (e && atoi(e) >= 4 && atoi(e) <= 8) g_attn_waves = atoi(e);
   e = getenv("P2V_GEMM_STAGES");
-  if (e && (atoi(e) == 0 || atoi(e) == 2 || atoi(e) == 3)) g_gemm_stages = atoi(e);
+  if (e && (atoi(e) == 2 || atoi(e) == 3)) g_gemm_stages = atoi(e);
   e = getenv("P2V_LN_GEMM");
   if (e) g_ln_gemm = atoi(e) != 0;
   e = getenv("P2V_LN_ROWS");

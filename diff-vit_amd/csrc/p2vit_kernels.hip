@@ -389,15 +389,14 @@ __device__ __forceinline__ void gemm_stage_epilogue(EpiLds* e, int n0, int tid, 
   }
 }
 
-template <int EPI, bool ASM_LDS = false>
-__device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n_tile, int nl, int h, const GemmArgs& g,
-                                                   const EpiLds* e, uint4 resv, const unsigned char* gtab = nullptr) {
+// EMBED and HEAD epilogues (one launch each per forward, k_gemm_i8); the per-block epilogues of the layer GEMMs are gemm_epilogue_tile2
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n_tile, int nl, int h, const GemmArgs& g, const EpiLds* e) {
+  static_assert(EPI == P2V_EPI_EMBED || EPI == P2V_EPI_HEAD, "stem / head epilogue");
   // lane owns output row m, channels n_tile + 8*gq + 4*h + {0..3}, gq = 0..3   (C/D map of 32x32 MFMA);
   // nl = n_tile - n0 (column offset inside the block tile, for the LDS constants)
   const bool row_ok = m < g.M;
   unsigned d[4];
-  unsigned res[4];
-  if (EPI == P2V_EPI_RESID) row16_to_halves(resv, res[0], res[1], res[2], res[3]);
   long long out_row = m;
   int tok = 0;
   if (EPI == P2V_EPI_EMBED) {
@@ -408,14 +407,8 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
     const int n = n_tile + 8 * gq + 4 * h, c = nl + 8 * gq + 4 * h;
-    float4 cs, bs;
-    if (ASM_LDS) {   // see gelu_tab_q8x4
-      const unsigned ea = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)(e->colscale + c);
-      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cs), "=&v"(bs) : "v"(ea));
-    } else {
-      cs = *reinterpret_cast<const float4*>(e->colscale + c);
-      bs = *reinterpret_cast<const float4*>(e->bias + c);
-    }
+    const float4 cs = *reinterpret_cast<const float4*>(e->colscale + c);
+    const float4 bs = *reinterpret_cast<const float4*>(e->bias + c);
     float y[4];
     // F.linear / F.conv2d on fake-quantised operands: exact integer sum * (s_x*s_w[n]), then ONE rounding
     // for the fp32 bias (layers.py:87,178).  The product int * 2^k is exact, so the fused multiply-add rounds
@@ -424,41 +417,8 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
     y[1] = __builtin_fmaf((float)acc[4 * gq + 1], cs.y, bs.y);
     y[2] = __builtin_fmaf((float)acc[4 * gq + 2], cs.z, bs.z);
     y[3] = __builtin_fmaf((float)acc[4 * gq + 3], cs.w, bs.w);
-    if ((EPI == P2V_EPI_REQUANT || EPI == P2V_EPI_GELU || EPI == P2V_EPI_GELU_TAB) && g.ep.tap_out && row_ok && n < g.N) {
-      // activation tap (qkv_output / fc1_output): the fp32 layer output.  REQUANT carries 2^e in its constants: undo it exactly
-      const float un = EPI == P2V_EPI_REQUANT ? 1.0f / g.ep.inv_s_out : 1.0f;
-      *reinterpret_cast<float4*>(g.ep.tap_out + (long long)m * g.N + n) = make_float4(y[0] * un, y[1] * un, y[2] * un, y[3] * un);
-    }
     float q[4];                 // integral floats; the byte packing below saturates to [-128,127]
-    if (EPI == P2V_EPI_GELU_TAB) {
-      d[gq] = gelu_tab_q8x4<ASM_LDS>(y, gtab, g.ep.gelu.k, g.ep.gelu.off, (float)(g.ep.gelu.cells - 1));
-      continue;
-    }
-    if (EPI == P2V_EPI_REQUANT) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) q[i] = rintf(y[i]);          // colscale and bias were pre-multiplied by 2^e (gemm_stage_epilogue)
-    } else if (EPI == P2V_EPI_GELU) {
-      gelu_q8x4(y, g.ep.inv_s_out, q);
-    } else if (EPI == P2V_EPI_RESID) {
-      // QAct(PTF) -> x + . -> QAct(PTF): non power-of-two per-channel scales, true fp32 divisions
-      const float4 sm = *reinterpret_cast<const float4*>(e->s_mid + c);
-      const float4 sr = *reinterpret_cast<const float4*>(e->s_res + c);
-      const float4 sn = *reinterpret_cast<const float4*>(e->s_next + c);
-      const float4 rm = *reinterpret_cast<const float4*>(e->r_mid + c);
-      const float4 rn = *reinterpret_cast<const float4*>(e->r_next + c);
-      const float smv[4] = {sm.x, sm.y, sm.z, sm.w}, srv[4] = {sr.x, sr.y, sr.z, sr.w}, snv[4] = {sn.x, sn.y, sn.z, sn.w};
-      const float rmv[4] = {rm.x, rm.y, rm.z, rm.w}, rnv[4] = {rn.x, rn.y, rn.z, rn.w};
-      const float4 mr = *reinterpret_cast<const float4*>(e->m128_sres + c);
-      const float mrv[4] = {mr.x, mr.y, mr.z, mr.w};
-      float q3[4], xs[4];
-      div_q8fx4<true>(y, smv, rmv, q3);                                // qact3 / mlp.qact2 (PTF) codes
-      // residual code * s_res with ONE rounding, from the biased byte: fma(u, s, -128 s) = RN((u - 128) s) = RN(code * s)
-      // (u*s is exact in the fma, -128*s is exact in fp32) -- v_cvt_f32_ubyteN + v_fma instead of bfe + cvt + mul
-      const unsigned ru = res[gq] ^ 0x80808080u;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xs[i] = __builtin_fmaf((float)((ru >> (8 * i)) & 255u), srv[i], mrv[i]) + q3[i] * smv[i];   // x + dequantised branch
-      div_q8fx4<false>(xs, snv, rnv, q);                               // Block.qact2 / qact4 (PTF)
-    } else if (EPI == P2V_EPI_EMBED) {
+    if (EPI == P2V_EPI_EMBED) {
       const float4 sn = *reinterpret_cast<const float4*>(e->s_next + c);
       const float4 rn = *reinterpret_cast<const float4*>(e->r_next + c);
       float4 pe = make_float4(0, 0, 0, 0);
@@ -483,7 +443,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
       }
     }
     d[gq] = pack4_sat(q[0], q[1], q[2], q[3]);
-    if (EPI == P2V_EPI_RESID || EPI == P2V_EPI_EMBED) __builtin_amdgcn_sched_barrier(0);   // keep the constant reads of the next group from being hoisted (register pressure)
+    if (EPI == P2V_EPI_EMBED) __builtin_amdgcn_sched_barrier(0);   // keep the constant reads of the next group from being hoisted (register pressure)
   }
   if (EPI != P2V_EPI_HEAD) {
     uint4 o = halves_to_row16(d[0], d[1], d[2], d[3]);
@@ -600,11 +560,10 @@ __device__ __forceinline__ void gemm_compute_tile(const int8_t* cx, const int8_t
   }
 }
 
-// Generic tiled GEMM: 128x128 block tile, 8 waves (2 along m x 4 along n, 64x32 each).  The fp32 epilogues are
-// dependent VALU chains: the measured issue rate of such chains on gfx950 is ~4.2 cycles/instruction at 2 waves
-// per SIMD and ~2.1 at 4 (tools/ubench/valu_rate.hip), so the kernel is shaped for <= 128 VGPRs -> 2 workgroups
-// (16 waves) per CU.  Global->LDS staging goes through a 3-deep ring of NAMED registers (an indexed array of
-// prefetch registers is placed in scratch by hipcc: measured), one barrier per k-tile.
+// Stem and head GEMM (EMBED / HEAD epilogues; one launch each per forward): 128x128 block tile, 8 waves (2 along m x 4 along n,
+// 64x32 each), <= 128 VGPRs -> 2 workgroups (16 waves) per CU.  Global->LDS staging goes through a 3-deep ring of NAMED registers
+// (an indexed array of prefetch registers is placed in scratch by hipcc: measured), one barrier per k-tile.  The layer GEMMs run
+// k_gemm_dma / k_ln_gemm.
 template <int EPI, bool W4>
 __global__ __launch_bounds__(512, 4) void k_gemm_i8(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) int8_t lds[2 * (GBM + GBN) * GBK + sizeof(EpiLds)];
@@ -657,15 +616,6 @@ __global__ __launch_bounds__(512, 4) void k_gemm_i8(GemmArgs g) {
   if (nk > 1) G_LOAD(b, 1);
   if (nk > 2) G_LOAD(c, 2);
   gemm_stage_epilogue<EPI>(sE, n0, tid, g);        // visible after the first barrier of the k loop
-  uint4 resv[2];                                   // residual codes of this lane's 2 output tiles, requested early
-  if (EPI == P2V_EPI_RESID) {
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 32 + 16 * h;
-      resv[mi] = make_uint4(0, 0, 0, 0);
-      if (m < g.M && n < g.N) resv[mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
-    }
-  }
   for (int kt = 0; kt < nk; kt += 3) {
     G_STEP(a, kt);
     if (kt + 1 < nk) G_STEP(b, kt + 1);
@@ -675,141 +625,12 @@ __global__ __launch_bounds__(512, 4) void k_gemm_i8(GemmArgs g) {
 #undef G_STEP
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
-    gemm_epilogue_tile<EPI>(acc[mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 32, wn * 32, h, g, sE,
-                            EPI == P2V_EPI_RESID ? resv[mi] : make_uint4(0, 0, 0, 0));
-}
-
-// one k-tile of MFMA work for a wave: 2 k-steps x (2 weight frags, 2 activation frags, 4 MFMAs)
-__device__ __forceinline__ void gemm_compute_tile_w4(const int8_t* cx, const int8_t* cw, int wm, int wn, int l31, int h, v16i (&acc)[2][2]) {
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    v4i fw[2], fx[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      fw[i] = *reinterpret_cast<const v4i*>(cw + lds_off64(wn * 64 + i * 32 + l31, 2 * ks + h));
-      fx[i] = *reinterpret_cast<const v4i*>(cx + lds_off64(wm * 64 + i * 32 + l31, 2 * ks + h));
-    }
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-        acc[ni][mi] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fw[ni], fx[mi], acc[ni][mi], 0, 0, 0);
-  }
-}
-
-// 4-wave variant of the tiled GEMM (2x2 waves of 64x64, <=168 VGPRs, 3 workgroups per CU): measured 4-10 % faster
-// than the 8-wave shape on fc1/qkv at batch 256, so it is the default (P2V_GEMM_WAVES=8 selects the other).
-// Global->LDS staging goes through a 3-deep ring of NAMED registers (an indexed array
-// of prefetch registers is placed in scratch by hipcc: measured, 80 B private segment and a scratch round trip
-// per k-tile): tile t+3 is requested while tile t is computed, one barrier per k-tile.
-#ifdef P2V_DIAG   // make diag: per-workgroup cycle stamps for tools/gemm_timeline.py; never in the product library
-#define P2V_STAMP(slot)                                                                         \
-  do {                                                                                          \
-    if (g.stamps && threadIdx.x == 0) g.stamps[(long long)blockIdx.x * 6 + (slot)] = __builtin_readcyclecounter(); \
-  } while (0)
-#else
-#define P2V_STAMP(slot) do { } while (0)
-#endif
-template <int EPI>
-__global__ __launch_bounds__(256, 3) void k_gemm_i8_w4(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) int8_t lds[2 * (GBM + GBN) * GBK + sizeof(EpiLds)];
-  int8_t* sX = lds;                    // [2][GBM][GBK] activation rows
-  int8_t* sW = lds + 2 * GBM * GBK;    // [2][GBN][GBK] weight rows
-  EpiLds* sE = reinterpret_cast<EpiLds*>(lds + 2 * (GBM + GBN) * GBK);
-  P2V_STAMP(0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order: each XCD walks a contiguous range of tiles, n fastest, so the tiles that share
-  // an activation panel hit the same L2.
-  int bid = blockIdx.x, nt = gridDim.x, xcd = bid & 7, qd = nt >> 3, rm = nt & 7;
-  int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-  const int tn = t % g.tiles_n, tm = t / g.tiles_n;
-  const int m0 = tm * GBM, n0 = tn * GBN;
-
-  const int lrow = tid >> 2, lchunk = tid & 3;
-  int mr0 = m0 + lrow, mr1 = m0 + lrow + 64;
-  mr0 = mr0 < g.M ? mr0 : g.M - 1;
-  mr1 = mr1 < g.M ? mr1 : g.M - 1;
-  const int8_t* gx0 = g.A + (long long)mr0 * g.lda + lchunk * 16;
-  const int8_t* gx1 = g.A + (long long)mr1 * g.lda + lchunk * 16;
-  const int8_t* gw0 = g.W + (long long)(n0 + lrow) * g.K + lchunk * 16;
-  const int8_t* gw1 = g.W + (long long)(n0 + lrow + 64) * g.K + lchunk * 16;
-  const int o0 = lds_off64(lrow, lchunk), o1 = lds_off64(lrow + 64, lchunk);
-
-  v16i acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
-
-  const int nk = g.K / GBK;
-  uint4 ax0, ax1, aw0, aw1, bx0, bx1, bw0, bw1, cx0, cx1, cw0, cw1;
-#define G_LOAD(P, T)                                                        \
-  do {                                                                      \
-    P##x0 = *reinterpret_cast<const uint4*>(gx0 + (T) * GBK);               \
-    P##x1 = *reinterpret_cast<const uint4*>(gx1 + (T) * GBK);               \
-    P##w0 = *reinterpret_cast<const uint4*>(gw0 + (T) * GBK);               \
-    P##w1 = *reinterpret_cast<const uint4*>(gw1 + (T) * GBK);               \
-  } while (0)
-#define G_STEP(P, T)                                                        \
-  do {                                                                      \
-    int8_t* bx_ = sX + ((T) & 1) * GBM * GBK;                               \
-    int8_t* bw_ = sW + ((T) & 1) * GBN * GBK;                               \
-    *reinterpret_cast<uint4*>(bx_ + o0) = P##x0;                            \
-    *reinterpret_cast<uint4*>(bx_ + o1) = P##x1;                            \
-    *reinterpret_cast<uint4*>(bw_ + o0) = P##w0;                            \
-    *reinterpret_cast<uint4*>(bw_ + o1) = P##w1;                            \
-    __syncthreads();                                                        \
-    if ((T) + 3 < nk) G_LOAD(P, (T) + 3);                                   \
-    gemm_compute_tile_w4(bx_, bw_, wm, wn, l31, h, acc);                       \
-  } while (0)
-  G_LOAD(a, 0);
-  if (nk > 1) G_LOAD(b, 1);
-  if (nk > 2) G_LOAD(c, 2);
-  gemm_stage_epilogue<EPI>(sE, n0, tid, g);        // visible after the first barrier of the k loop
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];   // GELU threshold table (cells * 8 bytes)
-  if (EPI == P2V_EPI_GELU_TAB)
-    for (int i = tid; i < g.ep.gelu.cells; i += 256)
-      reinterpret_cast<uint2*>(dyn_lds)[i] = reinterpret_cast<const uint2*>(g.ep.gelu.table)[i];
-  uint4 resv[2][2];                                // residual codes of this lane's 4 output tiles, requested early
-  if (EPI == P2V_EPI_RESID) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 64 + ni * 32 + 16 * h;
-        resv[ni][mi] = make_uint4(0, 0, 0, 0);
-        if (m < g.M && n < g.N) resv[ni][mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
-      }
-  }
-  P2V_STAMP(1);
-  for (int kt = 0; kt < nk; kt += 3) {
-    G_STEP(a, kt);
-    if (kt + 1 < nk) G_STEP(b, kt + 1);
-    if (kt + 2 < nk) G_STEP(c, kt + 2);
-  }
-#undef G_LOAD
-#undef G_STEP
-  __syncthreads();
-  P2V_STAMP(2);
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-      gemm_epilogue_tile<EPI>(acc[ni][mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, sE,
-                              EPI == P2V_EPI_RESID ? resv[ni][mi] : make_uint4(0, 0, 0, 0), dyn_lds);
-  P2V_STAMP(3);
-#ifdef P2V_DIAG
-  if (g.stamps && threadIdx.x == 0) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g.stamps[(long long)blockIdx.x * 6 + 4] = xcc; unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g.stamps[(long long)blockIdx.x * 6 + 5] = hw; }
-#endif
+    gemm_epilogue_tile<EPI>(acc[mi], m0 + wm * 64 + mi * 32 + l31, n0 + wn * 32, wn * 32, h, g, sE);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // K1d: the tiled GEMM with LDS-DMA staging (global_load_lds_dwordx4, gfx950).
-//   Why: in k_gemm_i8_w4 every k-tile moves 16 KB global -> VGPR -> ds_write_b128 -> LDS.  ds_write_b128 sustains ~79 B/clk per
+//   Why: in the register-staged round-1 kernel (removed) every k-tile moved 16 KB global -> VGPR -> ds_write_b128 -> LDS.  ds_write_b128 sustains ~79 B/clk per
 //   CU (13 cycles per wave-instruction), i.e. ~207 cycles of the CU's one LDS store path per workgroup and k-tile; with three
 //   workgroups per CU that is ~620 cycles per round of k-tiles beside 768 cycles of MFMA and ~380 cycles of fragment reads on the
 //   same LDS: the k-loop was bound by LDS, not by the matrix pipe (measured 1.1 k cycles per k-tile).  The DMA writes LDS without
@@ -1962,7 +1783,7 @@ __global__ __launch_bounds__(256) void k_gelu_err_sweep(unsigned first_bits, uns
 // host launchers (called from the C ABI in p2vit_capi.cpp)
 // ---------------------------------------------------------------------------------------------------
 int g_attn_waves = 8;     // P2V_ATTN_WAVES
-int g_gemm_stages = 3;    // P2V_GEMM_STAGES: 2 / 3 = LDS-DMA ring depth of k_gemm_dma, 0 = register-staged k_gemm_i8_w4
+int g_gemm_stages = 3;    // P2V_GEMM_STAGES: 2 / 3 = LDS-DMA ring depth of k_gemm_dma
 #ifdef P2V_DIAG
 unsigned long long* g_gemm_stamps = nullptr;
 #endif
@@ -2007,14 +1828,12 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
       case P2V_EPI_RESID: hipLaunchKernelGGL(KERNEL(P2V_EPI_RESID), grid4, block4, 0, st, g); break;                      \
       default: return -1;                                                                                                 \
     }
-#define P2V_K_W4(E) (k_gemm_i8_w4<E>)
 #define P2V_K_DMA2(E) (k_gemm_dma<E, 2, false>)
 #define P2V_K_DMA3(E) (k_gemm_dma<E, 3, false>)
 #define P2V_K_DMA3P(E) (k_gemm_dma<E, 3, true>)
     if (g.w4) { P2V_LAUNCH_TILED(P2V_K_DMA3P) }          // packed int4 weights: the LDS-DMA kernel only
     else if (g_gemm_stages == 2) { P2V_LAUNCH_TILED(P2V_K_DMA2) }
-    else if (g_gemm_stages == 3) { P2V_LAUNCH_TILED(P2V_K_DMA3) }
-    else { P2V_LAUNCH_TILED(P2V_K_W4) }
+    else { P2V_LAUNCH_TILED(P2V_K_DMA3) }
 #undef P2V_LAUNCH_TILED
     CHECK_LAUNCH();
     return 0;
