@@ -167,33 +167,9 @@ __device__ __forceinline__ int gelu_code_exact(float y, float inv_s) {
   asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:BYTE_" #B " dst_unused:" UNUSED              \
       " src0_sel:BYTE_0 src1_sel:BYTE_1"                                                                                   \
       : "+v"(DST) : "v"(YV), "v"(__uint_as_float(ENT.x)), "v"(ENT.y) : "vcc")
-// four outputs of one lane -> one dword of int8 codes.  ASM_LDS: the table is in LDS and is read with inline-asm ds_read_b64
-// (a kernel with LDS-DMA requests in flight: hipcc would put s_waitcnt vmcnt(0) in front of an LDS read it can see).
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
-template <bool ASM_LDS = false>
-__device__ __forceinline__ unsigned gelu_tab_q8x4(const float (&y)[4], const unsigned char* tab, float k, float off, float tmax) {
-  uint2 e[4];
-  if (ASM_LDS) {
-    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)tab;
-    v2u r0, r1, r2, r3;
-    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-                 : "v"(base + gelu_tab_offset(y[0], k, off, tmax)), "v"(base + gelu_tab_offset(y[1], k, off, tmax)),
-                   "v"(base + gelu_tab_offset(y[2], k, off, tmax)), "v"(base + gelu_tab_offset(y[3], k, off, tmax)));
-    e[0] = make_uint2(r0[0], r0[1]); e[1] = make_uint2(r1[0], r1[1]); e[2] = make_uint2(r2[0], r2[1]); e[3] = make_uint2(r3[0], r3[1]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = *reinterpret_cast<const uint2*>(tab + gelu_tab_offset(y[i], k, off, tmax));
-  }
-  unsigned d = 0;
-  P2V_GELU_SEL(0, "UNUSED_PAD", d, y[0], e[0]);
-  P2V_GELU_SEL(1, "UNUSED_PRESERVE", d, y[1], e[1]);
-  P2V_GELU_SEL(2, "UNUSED_PRESERVE", d, y[2], e[2]);
-  P2V_GELU_SEL(3, "UNUSED_PRESERVE", d, y[3], e[3]);
-  return d;
-}
-
-// two groups of four at once: all eight table reads are requested before the first select waits for one
+// eight outputs of one lane (two groups of four) -> two dwords of int8 codes: all eight table reads are requested before the first
+// select waits for one
 __device__ __forceinline__ void gelu_tab_q8x8(const float (&y0)[4], const float (&y1)[4], const unsigned char* tab, float k, float off, float tmax,
                                               unsigned& d0, unsigned& d1) {
   uint2 e0[4], e1[4];
@@ -262,14 +238,15 @@ __global__ void k_gelu_tab_finish(int cells, const unsigned* scratch, uint2* tab
 __global__ __launch_bounds__(256) void k_gelu_tab_check(float inv_s, float k, float off, float tmax, const unsigned char* table,
                                                         unsigned long long* mismatches) {
   unsigned long long bad = 0;
-  for (unsigned long long n = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; n < 2 * P2V_F32_FINITE;
-       n += (unsigned long long)gridDim.x * blockDim.x * 4) {
-    float y[4];
+  for (unsigned long long n = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * 8; n < 2 * P2V_F32_FINITE;
+       n += (unsigned long long)gridDim.x * blockDim.x * 8) {
+    float y[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = f32_in_order(n + i < 2 * P2V_F32_FINITE ? n + i : n);
-    const unsigned d = gelu_tab_q8x4(y, table, k, off, tmax);
+    for (int i = 0; i < 8; ++i) y[i >> 2][i & 3] = f32_in_order(n + i < 2 * P2V_F32_FINITE ? n + i : n);
+    unsigned d[2];
+    gelu_tab_q8x8(y[0], y[1], table, k, off, tmax, d[0], d[1]);          // the lookup of the GEMM epilogues
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bad += (sx8(d, i) != gelu_code_exact(y[i], inv_s)) ? 1 : 0;
+    for (int i = 0; i < 8; ++i) bad += (sx8(d[i >> 2], i & 3) != gelu_code_exact(y[i >> 2][i & 3], inv_s)) ? 1 : 0;
   }
   if (bad) atomicAdd(mismatches, bad);
 }
