@@ -70,8 +70,8 @@ def bench_swin(args, dva, dev, world, rank):
     plan = model.freeze(dev, bits=args.bits)
     B = args.batch
     x = base.repeat((B + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
-    import torch.distributed as dist
-    runner = dva.dp.DataParallelForward(lambda xs: plan.forward(xs, n_streams=args.streams), arch['num_classes'])
+    dist = args.dist
+    runner = dva.dp.DataParallelForward(lambda xs: plan.forward(xs, n_streams=args.streams), arch['num_classes'], always_gather=args.force_dist)
     out, gat = [None], [None]
 
     def step():
@@ -80,7 +80,7 @@ def bench_swin(args, dva, dev, world, rank):
 
     for _ in range(args.warmup):
         step()
-    times = timed_repeats(step, args.steps, args.repeats, world, dev, dist if world > 1 else None)
+    times = timed_repeats(step, args.steps, args.repeats, world, dev, dist)
     el = times[len(times) // 2]
     # roofline of the dominant op kind: one launch = one stream slice, timed by p2v_run_ops_profile (HIP events on the launch stream)
     n_sl = args.streams if (args.streams > 1 and B >= 16 * args.streams) else 1
@@ -109,14 +109,14 @@ def bench_swin(args, dva, dev, world, rank):
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8' if args.bits == 8 else 'int4w/int8a', 'data': 'synthetic',
             'config': {'workload': '%s PoT-PTQ forward, int%d weights, %dx%d, batch %d per GPU' % (args.model, args.bits, arch['img_size'], arch['img_size'], B),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'streams_per_gpu': args.streams,
-                       'collective': 'all_gather(logits)' if world > 1 else 'none'},
+                       'collective': 'all_gather(logits)' if dist is not None else 'none', 'backend': args.backend if dist is not None else None},
             'roofline': roof,
             'top1_agreement_fp32': round(float((out[0][:base.shape[0]].argmax(1).cpu() == fp32_top1).float().mean()), 4),
             'model_mfma_frac': round(model_ops / (el / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
             'kernel_ms_per_step': {k: round(n_sl * v[1], 3) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1][1])},
             'cpu_baseline': None, 'calibration': {'seconds': round(t_cal, 2), 'device': 'gpu'},
         }))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
@@ -136,20 +136,20 @@ def spawn_ranks(n):
 
 def timed_repeats(step, steps, repeats, world, dev, dist):
     """`repeats` timed loops of EXACTLY `steps` steps, each bracketed by barrier + torch.cuda.synchronize() on both sides; per loop
-    the MAX over ranks; returns the sorted per-loop seconds."""
+    the MAX over ranks; returns the sorted per-loop seconds.  `dist` is None when no process group exists."""
     out = []
     for _ in range(repeats):
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if dist is not None:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -169,6 +169,8 @@ def main():
     ap.add_argument('--streams', type=int, default=3, help='HIP streams the per-GPU batch is sliced over (3: one slice of 85-86 images is about one fused LayerNorm+GEMM workgroup per CU)')
     ap.add_argument('--model', default=MODEL, choices=('deit_tiny', 'deit_small', 'deit_base', 'vit_base', 'swin_tiny', 'swin_base'))
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for a rehearsal on one GPU)')
+    ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the all-gather of the logits even at '
+                    'world size 1 (under torch.distributed.run --nproc-per-node 1): exercises the RCCL branch on a one-GPU box')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -186,10 +188,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'RANK' not in os.environ:           # --force-dist without a launcher: a one-rank group on a free local port
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ.setdefault('MASTER_PORT', str(sk.getsockname()[1]))
+            os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
         dist.init_process_group(args.backend, **({'device_id': dev} if args.backend == 'nccl' else {}))
+    args.dist = dist
 
     if args.model.startswith('swin'):
         return bench_swin(args, dva, dev, world, rank)
@@ -226,7 +235,8 @@ def main():
     # == model(x, bits)[0]; the per-GPU batch runs as contiguous slices on their own HIP streams (images are independent; the kernels
     # of one slice fill the latency/VALU gaps of the others; 3 slices measured best: 92.3 vs 90.3 k img/s at 2, 67.7 k at 4).  The N-GPU step is the product's data-parallel runner: every rank forwards
     # its own shard, then ONE all-gather of the logits -- dp.DataParallelForward, the class the gloo tests exercise.
-    runner = dva.dp.DataParallelForward(lambda xs: plan.forward_streams(xs, bits, logits, args.streams), arch['num_classes'])
+    runner = dva.dp.DataParallelForward(lambda xs: plan.forward_streams(xs, bits, logits, args.streams), arch['num_classes'],
+                                        always_gather=args.force_dist)
     out = [None]
 
     def step():
@@ -234,11 +244,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    times = timed_repeats(step, args.steps, args.repeats, world, dev, dist if world > 1 else None)
+    times = timed_repeats(step, args.steps, args.repeats, world, dev, dist)
     el = times[len(times) // 2]                                      # median loop
     value = world * B * args.steps / el
     gather_ok = None
-    if world > 1:
+    if dist is not None:
         # the gathered tensor holds every rank's logits: rank 0 recomputes each shard itself (rank r's images come from seed 1000 + r)
         assert out[0].shape[0] == world * B and torch.equal(out[0][rank * B:(rank + 1) * B], logits)
         if rank == 0:
@@ -349,7 +359,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': args.model + ' PoT-PTQ forward, bit_config=[%d]*50, 224x224, batch %d per GPU' % (args.bits, B),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'streams_per_gpu': args.streams,
-                       'collective': 'all_gather(logits)' if world > 1 else 'none', 'backend': args.backend if world > 1 else None,
+                       'collective': 'all_gather(logits)' if dist is not None else 'none', 'backend': args.backend if dist is not None else None,
                        'gathered_logits_equal_per_rank_forwards': gather_ok},
             'roofline': roof,
             'top1_agreement_fp32': round(top1_fp32, 4),
@@ -359,7 +369,7 @@ def main():
             'calibration': {'seconds': round(t_cal, 2), 'device': 'host cpu (float pass + observer searches; harness.calibrate_model where=host)', 'tensors': len(ref_calib), 'tensors_bit_equal_reference': n_equal,
                             'scale_elements': n_elems, 'elements_off_by_a_power_of_two': exp_flips},
         }))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

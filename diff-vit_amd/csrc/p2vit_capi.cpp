@@ -36,6 +36,34 @@ static bool is_pot(float v) {
   return v > 0.f && frexpf(v, &ex) == 0.5f;
 }
 
+// ---- constant checks shared by the per-operator entry points and the plan setters: a plan that would make a kernel leave its
+//      exact range is refused when it is built, not when (or, through p2v_forward, never) an operator is called
+// exp_int = z * 2^(32-q) with z = r (r + b) + c: the kernels keep z exactly in fp32 and the table in int64
+static int check_lis_consts(const char* who, int x0_int, int b_int, int c_int) {
+  if (x0_int >= 0) return fail(P2V_E_ARG, "%s: x0_int must be negative", who);
+  if (c_int <= 0 || c_int >= (1 << 24) || b_int < 0 || b_int >= (1 << 23) || x0_int < -(1 << 12))
+    return fail(P2V_E_UNSUPPORTED, "%s: log-int-softmax constants out of range (x0 %d, b %d, c %d): softmax input scale below 2^-11?", who, x0_int,
+                b_int, c_int);
+  return P2V_OK;
+}
+static int check_requant_scale(const char* who, float inv_s_out) {
+  if (!(is_pot(inv_s_out) && inv_s_out >= 0x1p-40f && inv_s_out <= 0x1p40f))
+    return fail(P2V_E_UNSUPPORTED, "%s: REQUANT 1/scale %g must be a power of two (it is folded into the column scales)", who, inv_s_out);
+  return P2V_OK;
+}
+static int check_gelu_tab(const char* who, const p2v_gelu_tab& t) {
+  if (t.table && (t.cells <= 0 || t.cells > 4096)) return fail(P2V_E_ARG, "%s: GELU table with %d cells", who, t.cells);
+  return P2V_OK;
+}
+static int check_attn(const char* who, const p2v_attn& at) {
+  const int rc = check_lis_consts(who, at.x0_int, at.b_int, at.c_int);
+  if (rc != P2V_OK) return rc;
+  // the kernel folds s_q1^2 / s_attn into qk_scale: exact only for a power of two (both are PoT scales in the reference)
+  if (!is_pot(at.s_qkv_sq * at.inv_s_attn)) return fail(P2V_E_UNSUPPORTED, "%s: s_qkv_sq * inv_s_attn must be a power of two", who);
+  if (!(at.qk_scale > 0.f) || !(at.av_mul > 0.f)) return fail(P2V_E_ARG, "%s: qk_scale and av_mul must be positive", who);
+  return P2V_OK;
+}
+
 struct p2v_plan {
   p2v_model_desc d;
   int tokens, patches, k_patch, k_patch_pad, n_layers;
@@ -144,6 +172,20 @@ int p2v_plan_set_embed(p2v_plan* plan, float inv_s_input, const p2v_epilogue* e,
 int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk) {
   if (!plan || !blk) return fail(P2V_E_ARG, "p2v_plan_set_block: null argument");
   if (block < 0 || block >= plan->d.depth) return fail(P2V_E_ARG, "block %d out of range", block);
+  // p2v_forward launches the kernels directly: everything the per-operator entry points check is checked here, once
+  int rc = check_attn("p2v_plan_set_block: attn", blk->attn);
+  if (rc == P2V_OK) rc = check_gelu_tab("p2v_plan_set_block: gelu_fc1", blk->gelu_fc1);
+  for (int b = 0; b < 2 && rc == P2V_OK; ++b) rc = check_requant_scale("p2v_plan_set_block: inv_s_qkv", blk->inv_s_qkv[b]);
+  if (rc == P2V_OK && !(is_pot(blk->inv_s_fc1) && blk->inv_s_fc1 >= 0x1p-40f && blk->inv_s_fc1 <= 0x1p40f))
+    rc = fail(P2V_E_UNSUPPORTED, "p2v_plan_set_block: 1/scale of mlp.qact1 %g must be a power of two", blk->inv_s_fc1);
+  if (rc == P2V_OK && (!blk->proj_epi.s_mid || !blk->proj_epi.s_res || !blk->proj_epi.s_next || !blk->fc2_epi.s_mid || !blk->fc2_epi.s_res ||
+                       !blk->fc2_epi.s_next))
+    rc = fail(P2V_E_ARG, "p2v_plan_set_block: RESID epilogues need s_mid/s_res/s_next");
+  for (int i = 0; i < 6 && rc == P2V_OK; ++i) {
+    const p2v_ln& l = i < 2 ? blk->ln1[i] : blk->ln2[(i - 2) >> 1][(i - 2) & 1];
+    if (!l.mask || !l.gamma || !l.beta || !l.inv_out || !l.post_mul) rc = fail(P2V_E_ARG, "p2v_plan_set_block: LayerNorm constants missing");
+  }
+  if (rc != P2V_OK) return rc;
   plan->blocks[block] = *blk;
   plan->block_set[block] = 1;
   return P2V_OK;
@@ -151,6 +193,9 @@ int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk) {
 
 int p2v_plan_set_head(p2v_plan* plan, const p2v_ln* final_ln, float inv_s_out, float s_out) {
   if (!plan || !final_ln) return fail(P2V_E_ARG, "p2v_plan_set_head: null argument");
+  if (!final_ln->mask || !final_ln->gamma || !final_ln->beta || !final_ln->inv_out || !final_ln->post_mul)
+    return fail(P2V_E_ARG, "p2v_plan_set_head: LayerNorm constants missing");
+  if (!(inv_s_out > 0.f) || !(s_out > 0.f)) return fail(P2V_E_ARG, "p2v_plan_set_head: act_out scale must be positive");
   plan->final_ln = *final_ln;
   plan->head_inv_s = inv_s_out;
   plan->head_s = s_out;
@@ -381,9 +426,8 @@ int p2v_gemm_i8(int kind, const int8_t* A, int lda, int M, int K, int N, const p
   if (M <= 0 || N <= 0 || K <= 0 || K % GBK_PAD) return fail(P2V_E_SHAPE, "K=%d must be a positive multiple of %d", K, GBK_PAD);
   if (kind != P2V_EPI_HEAD && (N % 16 || ldo % 16)) return fail(P2V_E_UNSUPPORTED, "N and ldo must be multiples of 16 for int8 outputs");
   if (lda % 16) return fail(P2V_E_UNSUPPORTED, "lda must be a multiple of 16");
-  if (kind == P2V_EPI_REQUANT && !(is_pot(epi->inv_s_out) && epi->inv_s_out >= 0x1p-40f && epi->inv_s_out <= 0x1p40f))
-    return fail(P2V_E_UNSUPPORTED, "REQUANT: 1/scale %g must be a power of two (it is folded into the column scales)", epi->inv_s_out);
-  if (kind == P2V_EPI_GELU && epi->gelu.table && (epi->gelu.cells <= 0 || epi->gelu.cells > 4096)) return fail(P2V_E_ARG, "GELU table with %d cells", epi->gelu.cells);
+  if (kind == P2V_EPI_REQUANT && check_requant_scale("p2v_gemm_i8", epi->inv_s_out) != P2V_OK) return P2V_E_UNSUPPORTED;
+  if (kind == P2V_EPI_GELU && check_gelu_tab("p2v_gemm_i8", epi->gelu) != P2V_OK) return P2V_E_ARG;
   if (kind == P2V_EPI_RESID && (!epi->s_mid || !epi->s_res || !epi->s_next || !epi->residual)) return fail(P2V_E_ARG, "RESID epilogue needs s_mid/s_res/s_next/residual");
   if (kind == P2V_EPI_EMBED && (!epi->s_next || !epi->pos_deq || epi->patches <= 0)) return fail(P2V_E_ARG, "EMBED epilogue needs s_next/pos_deq/patches");
   return run_gemm(kind, A, lda, M, K, N, *lin, *epi, out, ldo, out_codes, (hipStream_t)stream);
@@ -404,9 +448,8 @@ int p2v_ln_gemm_i8(int kind, const int8_t* x, long long row_stride, int M, int C
   if (kind != P2V_EPI_REQUANT && kind != P2V_EPI_GELU) return fail(P2V_E_ARG, "p2v_ln_gemm_i8: epilogue %d (REQUANT and GELU are fused)", kind);
   if (M <= 0 || C <= 0 || N <= 0) return fail(P2V_E_SHAPE, "p2v_ln_gemm_i8: bad shape");
   if (C % 4 || row_stride % 4 || N % 16 || ldo != N) return fail(P2V_E_UNSUPPORTED, "p2v_ln_gemm_i8: C, row_stride multiples of 4; N multiple of 16; ldo == N");
-  if (kind == P2V_EPI_REQUANT && !(is_pot(epi->inv_s_out) && epi->inv_s_out >= 0x1p-40f && epi->inv_s_out <= 0x1p40f))
-    return fail(P2V_E_UNSUPPORTED, "REQUANT: 1/scale %g must be a power of two (it is folded into the column scales)", epi->inv_s_out);
-  if (kind == P2V_EPI_GELU && epi->gelu.table && (epi->gelu.cells <= 0 || epi->gelu.cells > 4096)) return fail(P2V_E_ARG, "GELU table with %d cells", epi->gelu.cells);
+  if (kind == P2V_EPI_REQUANT && check_requant_scale("p2v_ln_gemm_i8", epi->inv_s_out) != P2V_OK) return P2V_E_UNSUPPORTED;
+  if (kind == P2V_EPI_GELU && check_gelu_tab("p2v_ln_gemm_i8", epi->gelu) != P2V_OK) return P2V_E_ARG;
   read_env_once();
   LnArgs a{x, row_stride, M, C, *ln, ln_out, C};
   return run_ln_gemm(kind, a, *lin, *epi, N, out, (hipStream_t)stream);
@@ -421,10 +464,10 @@ int p2v_lis_attention(const int8_t* qkv, int batch, int tokens, int heads, int h
                       int8_t* probs_k, void* stream) {
   if (!qkv || !at || !out) return fail(P2V_E_ARG, "p2v_lis_attention: null argument");
   if (batch <= 0 || tokens <= 0 || heads <= 0) return fail(P2V_E_SHAPE, "bad attention shape");
-  if (at->x0_int >= 0) return fail(P2V_E_ARG, "x0_int must be negative");
-  // exp_int = z * 2^(32-q) with z = r (r + b) + c: the kernels keep z exactly in fp32 and the table in int64
-  if (at->c_int <= 0 || at->c_int >= (1 << 24) || at->b_int < 0 || at->b_int >= (1 << 23) || at->x0_int < -(1 << 12))
-    return fail(P2V_E_UNSUPPORTED, "log-int-softmax constants out of range (x0 %d, b %d, c %d): qact_attn1 scale below 2^-11?", at->x0_int, at->b_int, at->c_int);
+  {
+    const int rc = check_attn("p2v_lis_attention", *at);
+    if (rc != P2V_OK) return rc;
+  }
   AttnArgs a{qkv, batch, tokens, heads, *at, out, probs_k};
   return launch_rc(p2v_launch_attention(a, head_dim, (hipStream_t)stream), "lis_attention");
 }
@@ -450,9 +493,10 @@ int p2v_window_attention(const int8_t* qkv, int batch, int tokens_per_image, int
   if (head_dim != 32) return fail(P2V_E_UNSUPPORTED, "window attention: head_dim must be 32");
   if (wa->ws < 1 || wa->ws > 8 || wa->n_windows < 1 || wa->ws * wa->ws * wa->n_windows > tokens_per_image)
     return fail(P2V_E_SHAPE, "window attention: window size must be 1..8 and windows must fit the token count");
-  if (wa->x0_int >= 0) return fail(P2V_E_ARG, "x0_int must be negative");
-  if (wa->c_int <= 0 || wa->c_int >= (1 << 24) || wa->b_int < 0 || wa->b_int >= (1 << 23) || wa->x0_int < -(1 << 12))
-    return fail(P2V_E_UNSUPPORTED, "log-int-softmax constants out of range (x0 %d, b %d, c %d)", wa->x0_int, wa->b_int, wa->c_int);
+  {
+    const int rc = check_lis_consts("p2v_window_attention", wa->x0_int, wa->b_int, wa->c_int);
+    if (rc != P2V_OK) return rc;
+  }
   const float pots[5] = {wa->s_q1, wa->s_attn, wa->s_table, wa->s_q2, wa->s_q3};
   for (float s : pots) {
     int ex;

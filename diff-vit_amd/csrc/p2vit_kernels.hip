@@ -1794,7 +1794,24 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   const int tiles_m = (g.M + GBM - 1) / GBM;
   if (epi != P2V_EPI_HEAD && epi != P2V_EPI_EMBED) {
     dim3 grid4(g.tiles_n * tiles_m), block4(256);
-    const unsigned tab_bytes = (epi == P2V_EPI_GELU && g.ep.gelu.table) ? (unsigned)g.ep.gelu.cells * 8u : 0u;
+    unsigned tab_bytes = (epi == P2V_EPI_GELU && g.ep.gelu.table) ? (unsigned)g.ep.gelu.cells * 8u : 0u;
+    // static LDS of the GELU_TAB instantiations (ring + column constants) plus the table can pass the 64 KB a kernel gets by default
+    // (1/scale = 256: 2111 cells = 16.5 KB): ask for the larger dynamic block once per process and device, or use the arithmetic epilogue
+    if (tab_bytes && g_gemm_stages * DMA_STAGE_BYTES + 2 * GBN * (int)sizeof(float) + (int)tab_bytes > 64 * 1024) {
+      static int granted[16][3] = {{0}};
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+      const int which = g.w4 ? 2 : (g_gemm_stages == 2 ? 0 : 1);
+      if (dev < 0 || (int)tab_bytes > granted[dev][which]) {
+        const void* fn = g.w4 ? reinterpret_cast<const void*>(&k_gemm_dma<P2V_EPI_GELU_TAB, 3, true>)
+                              : (g_gemm_stages == 2 ? reinterpret_cast<const void*>(&k_gemm_dma<P2V_EPI_GELU_TAB, 2, false>)
+                                                    : reinterpret_cast<const void*>(&k_gemm_dma<P2V_EPI_GELU_TAB, 3, false>));
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes) != hipSuccess) {
+          (void)hipGetLastError();
+          tab_bytes = 0;                          // arithmetic P2V_EPI_GELU kernel: same codes, no table
+        } else if (dev >= 0) granted[dev][which] = (int)tab_bytes;
+      }
+    }
 #define P2V_LAUNCH_TILED(KERNEL)                                                                                          \
     switch (epi) {                                                                                                        \
       case P2V_EPI_REQUANT: hipLaunchKernelGGL(KERNEL(P2V_EPI_REQUANT), grid4, block4, 0, st, g); break;                  \

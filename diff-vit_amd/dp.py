@@ -21,10 +21,12 @@ class DataParallelForward:
     """``forward_fn(local_images) -> local_logits`` on every rank, then all-gather.  ``forward_fn`` is the product's
     quantized forward on GPU ranks (``lambda x: model(x, bits)[0]``)."""
 
-    def __init__(self, forward_fn, num_classes, group=None):
+    def __init__(self, forward_fn, num_classes, group=None, always_gather=False):
+        """``always_gather``: run the collective even in a one-rank group (exercises the RCCL path on a single GPU)."""
         self.fn = forward_fn
         self.num_classes = num_classes
         self.group = group
+        self.always_gather = bool(always_gather) and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -46,7 +48,7 @@ class DataParallelForward:
 
     def local(self, local_images, global_n):
         out = self.fn(local_images)
-        if self.world == 1:
+        if self.world == 1 and not self.always_gather:
             return out
         sizes = [shard_bounds(global_n, self.world, r) for r in range(self.world)]
         counts = [b - a for a, b in sizes]

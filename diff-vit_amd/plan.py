@@ -45,7 +45,12 @@ def lis_consts(sf):
     x0 = torch.floor(-0.6931 / sf)
     b = torch.floor((0.96963238 / 0.35815147) / sf)
     c = torch.floor((1. / 0.35815147) / sf**2)
-    return int(x0), int(b), int(c)
+    x0, b, c = int(x0), int(b), int(c)
+    # the kernels keep z = r (r + b) + c exactly in fp32 and the exp table in int64 (include/p2vit.h, Limits): refuse at plan time
+    if not (-(1 << 12) <= x0 < 0 and 0 <= b < (1 << 23) and 0 < c < (1 << 24)):
+        raise NotImplementedError('log-int-softmax input scale %g is outside the exact range of the attention kernel '
+                                  '(x0_int %d, b_int %d, c_int %d; scales from 2^-11 up are covered)' % (float(sf), x0, b, c))
+    return x0, b, c
 
 
 class FrozenPlan:

@@ -19,12 +19,9 @@ def _pad128(n):
 
 
 def _lis_consts(sf):
-    """x0_int, b_int, c_int of the I-BERT polynomial in fp32 (layers.py:334-351)."""
-    sf = torch.tensor(float(sf), dtype=torch.float32)
-    x0 = torch.floor(-0.6931 / sf)
-    b = torch.floor((0.96963238 / 0.35815147) / sf)
-    c = torch.floor((1. / 0.35815147) / sf ** 2)
-    return int(x0), int(b), int(c)
+    """x0_int, b_int, c_int of the I-BERT polynomial in fp32 (layers.py:334-351); range-checked like the ViT plan's."""
+    from .plan import lis_consts
+    return lis_consts(torch.tensor(float(sf), dtype=torch.float32))
 
 
 def _window_index(H, W, ws, shift):

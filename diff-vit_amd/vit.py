@@ -335,15 +335,23 @@ class VisionTransformer(nn.Module):
         return self.head
 
     # ---- state switches (vit_fquant.py:667-698) ----------------------------------------------------------------
-    def _q_modules(self):
-        if self._qmods is None:               # the module tree is fixed after construction
+    def __setattr__(self, name, value):
+        # replacing a submodule (e.g. swapping the head) invalidates the cached module lists and the frozen plan; the reference walks
+        # self.modules() on every state switch (vit_fquant.py:667-698)
+        if isinstance(value, nn.Module) and '_qmods' in self.__dict__:
+            self.__dict__['_qmods'] = self.__dict__['_lnmods'] = self.__dict__['_plan'] = None
+        super().__setattr__(name, value)
+
+    def _q_modules(self, refresh=False):
+        if self._qmods is None or refresh:    # cached for the per-forward check only; every state switch below walks the tree again
             self._qmods = [m for m in self.modules() if type(m) in (QConv2d, QLinear, QAct, QIntSoftmax)]
+            self._lnmods = None
         return self._qmods
 
     def model_quant(self, flag='on'):
         if flag == 'on':
             self.quant = True
-        for m in self._q_modules():
+        for m in self._q_modules(refresh=True):
             m.quant = True
         if self.cfg.INT_NORM and flag != 'off':
             for m in self.modules():
@@ -352,20 +360,20 @@ class VisionTransformer(nn.Module):
         self._plan = None
 
     def model_dequant(self):
-        for m in self._q_modules():
+        for m in self._q_modules(refresh=True):
             m.quant = False
 
     def model_open_calibrate(self):
-        for m in self._q_modules():
+        for m in self._q_modules(refresh=True):
             m.calibrate = True
         self._plan = None
 
     def model_open_last_calibrate(self):
-        for m in self._q_modules():
+        for m in self._q_modules(refresh=True):
             m.last_calibrate = True
 
     def model_close_calibrate(self):
-        for m in self._q_modules():
+        for m in self._q_modules(refresh=True):
             m.calibrate = False
 
     def load_state_dict(self, *a, **k):

@@ -47,6 +47,71 @@ def test_error_conventions_without_gpu():
     L.p2v_plan_destroy(h)
 
 
+def test_plan_refuses_out_of_range_constants_at_plan_time():
+    """p2v_forward launches the kernels directly, so what the per-operator entry points check (softmax constants inside the exact
+    range, power-of-two REQUANT scale, GELU table size) is checked by the plan setters; the Python freeze refuses even earlier."""
+    import torch
+    import diff_vit_amd
+    from diff_vit_amd import plan as P
+    E = diff_vit_amd.engine
+    L = E.lib()
+    assert P.lis_consts(torch.tensor(2.0 ** -11)) == (-1420, 5544, 11710978)
+    with pytest.raises(NotImplementedError):
+        P.lis_consts(torch.tensor(2.0 ** -12))                              # c_int = 46.8 M >= 2^24: z leaves the exact fp32 range
+    h = ctypes.c_void_p()
+    ok = E.ModelDesc(E.P2V_ABI_VERSION, 224, 16, 3, 384, 12, 6, 1536, 1000)
+    E.check(L.p2v_plan_create(ctypes.byref(ok), ctypes.byref(h)))
+    one = ctypes.c_void_p(16)
+
+    def block(s_attn=2.0 ** -4, inv_qkv=16.0, cells=300, inv_fc1=8.0):
+        b = E.Block()
+        ln = E.Ln(1.0, one, one, one, one, one, None)
+        for i in range(2):
+            b.ln1[i] = ln
+            b.inv_s_qkv[i] = inv_qkv
+            for j in range(2):
+                b.ln2[i][j] = ln
+        x0, bb, cc = [int(v) for v in (torch.floor(-0.6931 / torch.tensor(s_attn)), torch.floor((0.96963238 / 0.35815147) / torch.tensor(s_attn)),
+                                       torch.floor((1. / 0.35815147) / torch.tensor(s_attn) ** 2))]
+        b.attn = E.Attn(2.0 ** -8, 0.125, 1.0 / s_attn, 0.5, x0, bb, cc)
+        for e in (b.proj_epi, b.fc2_epi):
+            e.s_mid, e.s_res, e.s_next = one, one, one
+        b.inv_s_fc1 = inv_fc1
+        b.gelu_fc1 = E.GeluTab(one, 16.0, 100.0, cells)
+        return b
+
+    E.check(L.p2v_plan_set_block(h, 0, ctypes.byref(block())))
+    with pytest.raises(NotImplementedError):                                # qact_attn1 scale 2^-12: refused when the plan is built
+        E.check(L.p2v_plan_set_block(h, 0, ctypes.byref(block(s_attn=2.0 ** -12))))
+    assert b'log-int-softmax constants out of range' in L.p2v_last_error()
+    with pytest.raises(NotImplementedError):                                # REQUANT folds 1/scale into the column constants
+        E.check(L.p2v_plan_set_block(h, 0, ctypes.byref(block(inv_qkv=12.0))))
+    with pytest.raises(E.P2VError):                                         # table larger than the kernels' LDS budget
+        E.check(L.p2v_plan_set_block(h, 0, ctypes.byref(block(cells=5000))))
+    with pytest.raises(NotImplementedError):
+        E.check(L.p2v_plan_set_block(h, 0, ctypes.byref(block(inv_fc1=3.0))))
+    L.p2v_plan_destroy(h)
+
+
+def test_module_cache_follows_replaced_submodules():
+    """state switches walk the module tree like the reference (vit_fquant.py:667-698): a replaced head is not skipped."""
+    import diff_vit_amd as dva
+    a = dva.synth.ARCHS['micro']
+    from functools import partial
+    m = dva.VisionTransformer(img_size=a['img_size'], patch_size=a['patch_size'], embed_dim=a['embed_dim'], depth=a['depth'],
+                              num_heads=a['num_heads'], num_classes=a['num_classes'], mlp_ratio=a['mlp_ratio'], qkv_bias=True,
+                              norm_layer=partial(dva.QIntLayerNorm, eps=1e-6), input_quant=True, cfg=dva.Config())
+    m.model_quant()
+    old = m.head
+    m.head = dva.QLinear(a['embed_dim'], 7)
+    assert m._qmods is None and m._plan is None
+    m.model_quant()
+    assert m.head.quant and m.head in m._q_modules() and old not in m._q_modules()
+    m.blocks[0].attn.proj = dva.QLinear(a['embed_dim'], a['embed_dim'])     # a nested replacement: caught by the next state switch
+    m.model_open_calibrate()
+    assert m.blocks[0].attn.proj.calibrate
+
+
 def test_custom_ops_registered_and_gpu_only():
     """torch.ops.p2vit.* exist after import and have no CPU kernel (no silent fallback)."""
     import torch

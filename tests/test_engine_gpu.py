@@ -516,7 +516,12 @@ def test_dropin_flow_matches_reference(dva, micro, calib_device):
     g = micro['g']
     m = _build_micro(dva, micro).to(calib_device)
     out_cal, _, gd = dva.harness.calibrate_model(m, micro['x_cal'].to(calib_device), where='model')     # on calib_device itself
-    assert np.abs(out_cal.cpu().numpy() - g['calib_logits']).max() <= 1e-4
+    # float calibration pass (north_star: within 1e-5 of the reference's): the host pass is the reference's own torch-CPU arithmetic;
+    # the pass on the GPU runs rocBLAS / MIOpen-free torch-ROCm fp32 kernels whose accumulation order differs from MKL's, which the
+    # discrete log-int-softmax on float scores amplifies: bounded at 1e-4 there, measured value printed
+    d_cal = float(np.abs(out_cal.cpu().numpy() - g['calib_logits']).max())
+    print('calibration logits max|d| on %s: %.3g' % (calib_device, d_cal))
+    assert d_cal <= (1e-5 if calib_device == 'cpu' else 1e-4)
     calib = m.export_calib()
     flat = dva.calib_io.flatten(calib)
     for k, v in flat.items():
@@ -591,25 +596,37 @@ def test_deit_small_calibration_on_the_gpu_box(dva, oracle, synth):
         dva.harness.calibrate_model(m, x.cuda(), where=where)
         assert next(m.parameters()).is_cuda
         flat = dva.calib_io.flatten(m.export_calib())
-        flips, early = 0, 0
+        flips, early, early_rel, off, worst = 0, 0, 0.0, 0, 0.0
         for k, want in ref.items():
             a = flat[k].numpy().reshape(want.shape)
+            is_early = k.startswith(('qact', 'patch_embed') + tuple('blocks.%d.' % i for i in range(7))) and not k.startswith('qact2')
             if np.all(np.frexp(want)[0] == 0.5):
                 n = int((a != want).sum())
             else:                         # PTF: float base scale x {1,2,4,8}
                 n = int((np.round(a / a.min()) != np.round(want / want.min())).sum())
-                assert np.abs(a / want - 1).max() < 1.05 or n, (where, k)
+                rel = abs(float(a.min()) / float(want.min()) - 1.0)          # the base scale 2 max|x| / 255 of the calibration batch
+                worst = max(worst, rel)
+                off += int(rel > 1e-3)
+                if is_early:
+                    early_rel = max(early_rel, rel)
             flips += n
-            if k.startswith(('qact', 'patch_embed', 'blocks.0.', 'blocks.1.', 'blocks.2.', 'blocks.3.')) and not k.startswith('qact2'):
+            if is_early and (not k.startswith('blocks.') or int(k.split('.')[1]) < 4):
                 early += n
-        return flips, early, m
+        return flips, early, early_rel, off, worst, m
 
-    flips, early, m = run('host')
+    flips, early, early_rel, off, worst, m = run('host')
+    print('host calibration vs the Xeon fixture: %d exponent flips (%d before block 4), PTF base scales: worst %.2e before block 7, '
+          '%d tensors beyond 1e-3, worst overall %.2e' % (flips, early, early_rel, off, worst))
+    # exponents: a few dozen of 243 944 and none through block 3; PTF base scales: within 1 % for every tensor before block 7 (measured
+    # 0 there), at most 20 tensors more than 1e-3 away overall (measured 9 factor differences, largest deviation 0.35 % at
+    # blocks.9.attn.qact3) and none more than 2 % away -- a real regression of the observer or of the float pass breaks every one of these
     assert flips <= 60 and early == 0, (flips, early)
+    assert early_rel < 1e-2 and off <= 20 and worst < 2e-2, (early_rel, off, worst)
     out = m(synth.images(seed, 2, 224, offset=1000).cuda(), [8] * 50)[0]       # the frozen plan builds from host-side scales
     assert out.shape == (2, 1000) and bool(torch.isfinite(out).all())
-    flips_gpu, _, _ = run('model')
-    assert flips_gpu <= 600, flips_gpu
+    flips_gpu, _, _, _, worst_gpu, _ = run('model')
+    print('all-GPU calibration: %d exponent flips, worst PTF base deviation %.2e' % (flips_gpu, worst_gpu))
+    assert flips_gpu <= 600 and worst_gpu < 5e-2, (flips_gpu, worst_gpu)
 
 
 def test_module_level_quant_ops_on_gpu(dva):
@@ -985,3 +1002,27 @@ def test_bench_two_ranks_on_one_gpu_gloo(dva):
     assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak' and d['config']['global_batch'] == 24
     assert d['config']['gathered_logits_equal_per_rank_forwards'] is True
     assert d['value'] > 0 and 'roofline' in d and d['cpu_baseline'] is None
+
+
+def test_bench_rccl_branch_on_one_gpu(dva):
+    """the RCCL branch of the multi-GPU step on hardware before any 8-GPU node sees it: one rank under `torch.distributed.run`
+    (a fresh child process, never an exec of one that touched the GPU) with --backend nccl --force-dist, so
+    init_process_group('nccl', device_id=...), the device-side all_gather_into_tensor of the logits and the dmabuf IPC
+    environment (HSA_ENABLE_IPC_MODE_LEGACY=0) run exactly as at N = 8, and the gathered tensor equals the rank's own forward."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '1', '--backend', 'nccl', '--force-dist',
+                        '--steps', '2', '--warmup', '1', '--repeats', '2', '--batch', '24', '--model', 'deit_tiny', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['config']['backend'] == 'nccl' and d['config']['collective'] == 'all_gather(logits)'
+    assert d['config']['gathered_logits_equal_per_rank_forwards'] is True and d['value'] > 0

@@ -41,10 +41,16 @@ def _dp_worker(rank, world, port, n, q):
     import diff_vit_amd as dva
     torch.manual_seed(0)
     w = torch.randn(7, 3 * 8 * 8)
+    calls = []
     fn = lambda x: x.reshape(x.shape[0], -1) @ w.t()           # stand-in forward (the GPU engine is not available on CPU)
     x = dva.synth.images(5, n, 8)
-    runner = dva.dp.DataParallelForward(fn, 7)
+    runner = dva.dp.DataParallelForward(fn, 7, always_gather=(world == 1))
+    if world == 1:                                             # the one-rank group still goes through the collective (bench.py --force-dist)
+        real = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     out = runner(x)
+    if world == 1:
+        assert calls == [1]
     if rank == 0:
         q.put((out.numpy(), fn(x).numpy()))
     dist.barrier()
@@ -64,3 +70,14 @@ def test_data_parallel_allgather_gloo(n):
         p.join(60)
         assert p.exitcode == 0
     assert np.array_equal(got, ref)          # even (all_gather_into_tensor) and ragged (all_gather) global batches
+
+
+def test_one_rank_group_still_gathers():
+    """bench.py --force-dist: a one-rank process group runs the all-gather (the RCCL branch on a single GPU; gloo here)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_dp_worker, args=(0, 1, 29500 + (os.getpid() + 31) % 2000, 6, q))
+    p.start()
+    got, ref = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0 and np.array_equal(got, ref)

@@ -5,6 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 LIB=diff-vit_amd/csrc/libp2vit_hip.so
 cp $LIB /tmp/p2v_new.so
+trap 'cp /tmp/p2v_new.so $LIB' EXIT      # a failing run must not leave the baseline binary installed
 BASE=$1; shift
 for r in 1 2 3; do
   for v in base new; do
