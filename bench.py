@@ -169,6 +169,7 @@ def main():
     ap.add_argument('--streams', type=int, default=3, help='HIP streams the per-GPU batch is sliced over (3: one slice of 85-86 images is about one fused LayerNorm+GEMM workgroup per CU)')
     ap.add_argument('--model', default=MODEL, choices=('deit_tiny', 'deit_small', 'deit_base', 'vit_base', 'swin_tiny', 'swin_base'))
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for a rehearsal on one GPU)')
+    ap.add_argument('--slices', default=None, help='explicit batch slices, e.g. 83,83,83,7 (default: FrozenPlan.slice_sizes)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the all-gather of the logits even at '
                     'world size 1 (under torch.distributed.run --nproc-per-node 1): exercises the RCCL branch on a one-GPU box')
     args = ap.parse_args()
@@ -235,7 +236,8 @@ def main():
     # == model(x, bits)[0]; the per-GPU batch runs as contiguous slices on their own HIP streams (images are independent; the kernels
     # of one slice fill the latency/VALU gaps of the others; 3 slices measured best: 92.3 vs 90.3 k img/s at 2, 67.7 k at 4).  The N-GPU step is the product's data-parallel runner: every rank forwards
     # its own shard, then ONE all-gather of the logits -- dp.DataParallelForward, the class the gloo tests exercise.
-    runner = dva.dp.DataParallelForward(lambda xs: plan.forward_streams(xs, bits, logits, args.streams), arch['num_classes'],
+    slices = [int(v) for v in args.slices.split(',')] if args.slices else plan.slice_sizes(B, args.streams)
+    runner = dva.dp.DataParallelForward(lambda xs: plan.forward_streams(xs, bits, logits, args.streams, slices), arch['num_classes'],
                                         always_gather=args.force_dist)
     out = [None]
 
@@ -257,22 +259,22 @@ def main():
             for r in range(world):
                 br = dva.synth.images(1000 + r, args.batch, arch['img_size'])
                 xr = br.repeat((B + br.shape[0] - 1) // br.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
-                plan.forward_streams(xr, bits, chk, args.streams)
+                plan.forward_streams(xr, bits, chk, args.streams, slices)
                 gather_ok = gather_ok and bool(torch.equal(chk, out[0][r * B:(r + 1) * B]))
-            plan.forward_streams(x, bits, logits, args.streams)       # restore this rank's logits for the checks below
+            plan.forward_streams(x, bits, logits, args.streams, slices)       # restore this rank's logits for the checks below
     top1_fp32 = float((logits[:base.shape[0]].argmax(1).cpu() == fp32_top1).float().mean())   # BASELINE metric: top-1 vs fp32
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, measured live ----------------------
     # One LAUNCH in the timed region covers one batch slice (B / streams images, forward_streams): the profile pass times
     # exactly those launches - same kernels, same shapes - with events recorded on the launch stream between consecutive
     # launches, so its average agrees with the rocprofv3 --kernel-trace average of this command (profiles/).
-    n_sl = args.streams if (args.streams > 1 and B >= 2 * args.streams) else 1
-    Bl = (B + n_sl - 1) // n_sl
+    n_sl = len(slices)
+    Bl = max(slices)
     prof = {}
     for _ in range(5):
         for kind, ms in plan.profile(x[:Bl], bits):
             prof.setdefault(kind, []).append(ms)
-    tot = {k: n_sl * sum(v) / 5 for k, v in prof.items()}        # per step: every slice issues the same launches
+    tot = {k: n_sl * sum(v) / 5 for k, v in prof.items()}        # per step: every slice issues the same launches (a smaller last slice is charged like a full one)
     dom = max(tot, key=tot.get)
     avg_ms = sum(prof[dom]) / len(prof[dom])
     ops, byts = algorithmic_work(dom, arch, Bl, args.bits)
@@ -358,7 +360,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int%d' % args.bits if args.bits == 8 else 'int4w/int8a',
             'data': 'synthetic',
             'config': {'workload': args.model + ' PoT-PTQ forward, bit_config=[%d]*50, 224x224, batch %d per GPU' % (args.bits, B),
-                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'streams_per_gpu': args.streams,
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'streams_per_gpu': args.streams, 'batch_slices': slices,
                        'collective': 'all_gather(logits)' if dist is not None else 'none', 'backend': args.backend if dist is not None else None,
                        'gathered_logits_equal_per_rank_forwards': gather_ok},
             'roofline': roof,

@@ -89,6 +89,7 @@ extern int g_ln_rows;
 extern int g_attn_waves;
 extern int g_gemm_stages;
 extern int g_ln_gemm;
+extern int g_ln_gemm_ver;
 // Tuning / A-B switches read once per process (first plan or first version query).  None of them changes results:
 // P2V_LN_GENERIC forces the generic LayerNorm chain (bit-identical to the fast one, both are tested).
 static void read_env_once() {
@@ -101,12 +102,26 @@ static void read_env_once() {
   if (e && (atoi(e) == 2 || atoi(e) == 3)) g_gemm_stages = atoi(e);
   e = getenv("P2V_LN_GEMM");
   if (e) g_ln_gemm = atoi(e) != 0;
+  e = getenv("P2V_LN_GEMM_V");
+  if (e && atoi(e) >= 1 && atoi(e) <= 3) g_ln_gemm_ver = atoi(e);
   e = getenv("P2V_LN_ROWS");
   if (e && atoi(e) >= 1 && atoi(e) <= 64) g_ln_rows = atoi(e);
   e = getenv("P2V_LN_GENERIC");
   if (e && atoi(e) == 1) g_ln_generic = 1;
 }
 int p2v_abi_version(void) { read_env_once(); return P2V_ABI_VERSION; }
+
+int p2v_set_tuning(const char* name, int value) {
+  if (!name) return fail(P2V_E_ARG, "p2v_set_tuning: null name");
+  read_env_once();                      // an explicit setting wins over the environment
+  if (!strcmp(name, "ln_gemm")) { g_ln_gemm = value != 0; return P2V_OK; }
+  if (!strcmp(name, "ln_gemm_version") && value >= 1 && value <= 3) { g_ln_gemm_ver = value; return P2V_OK; }
+  if (!strcmp(name, "ln_generic")) { g_ln_generic = value != 0; return P2V_OK; }
+  if (!strcmp(name, "ln_rows") && value >= 1 && value <= 64) { g_ln_rows = value; return P2V_OK; }
+  if (!strcmp(name, "attn_waves") && value >= 4 && value <= 8) { g_attn_waves = value; return P2V_OK; }
+  if (!strcmp(name, "gemm_stages") && (value == 2 || value == 3)) { g_gemm_stages = value; return P2V_OK; }
+  return fail(P2V_E_ARG, "p2v_set_tuning: unknown switch or value out of range: %s = %d", name, value);
+}
 const char* p2v_last_error(void) { return g_err; }
 
 int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
@@ -390,24 +405,51 @@ int p2v_forward_taps(p2v_plan* p, const float* images, int batch, const int8_t* 
   return forward_impl(p, images, batch, bit_config, n_cfg, logits, workspace, workspace_bytes, -1, stream, nullptr, qkv_out, fc1_out);
 }
 
+static int prof_collect(Prof& prof, float* ms_out, int32_t* kind_out, int max_launches) {
+  hipEventSynchronize(prof.ev.back());
+  const int n = (int)prof.kind.size();
+  for (int i = 0; i < n && i < max_launches; ++i) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, prof.ev[i], prof.ev[i + 1]);
+    ms_out[i] = ms;
+    kind_out[i] = prof.kind[i];
+  }
+  return n;
+}
+
 int p2v_forward_profile(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
                         size_t workspace_bytes, void* stream, float* ms_out, int32_t* kind_out, int max_launches) {
   if (!ms_out || !kind_out || max_launches <= 0) return fail(P2V_E_ARG, "p2v_forward_profile: null argument");
   Prof prof;
   int rc = forward_impl(p, images, batch, bit_config, n_cfg, logits, workspace, workspace_bytes, -1, stream, &prof);
   int n = 0;
-  if (rc == P2V_OK) {
-    hipEventSynchronize(prof.ev.back());
-    n = (int)prof.kind.size();
-    for (int i = 0; i < n && i < max_launches; ++i) {
-      float ms = 0.f;
-      hipEventElapsedTime(&ms, prof.ev[i], prof.ev[i + 1]);
-      ms_out[i] = ms;
-      kind_out[i] = prof.kind[i];
-    }
-  }
+  if (rc == P2V_OK) n = prof_collect(prof, ms_out, kind_out, max_launches);
   for (hipEvent_t e : prof.ev) hipEventDestroy(e);
   return rc == P2V_OK ? n : rc;
+}
+
+int p2v_forward_profile_begin(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
+                              size_t workspace_bytes, void* stream, void** token) {
+  if (!token) return fail(P2V_E_ARG, "p2v_forward_profile_begin: null argument");
+  Prof* prof = new Prof();
+  const int rc = forward_impl(p, images, batch, bit_config, n_cfg, logits, workspace, workspace_bytes, -1, stream, prof);
+  if (rc != P2V_OK) {
+    for (hipEvent_t e : prof->ev) hipEventDestroy(e);
+    delete prof;
+    *token = nullptr;
+    return rc;
+  }
+  *token = prof;
+  return P2V_OK;
+}
+
+int p2v_forward_profile_end(void* token, float* ms_out, int32_t* kind_out, int max_launches) {
+  if (!token || !ms_out || !kind_out || max_launches <= 0) return fail(P2V_E_ARG, "p2v_forward_profile_end: null argument");
+  Prof* prof = reinterpret_cast<Prof*>(token);
+  const int n = prof_collect(*prof, ms_out, kind_out, max_launches);
+  for (hipEvent_t e : prof->ev) hipEventDestroy(e);
+  delete prof;
+  return n;
 }
 
 // ---- per-operator entry points ------------------------------------------------------------------------

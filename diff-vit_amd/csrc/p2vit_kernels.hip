@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "p2vit_kernels.h"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -24,12 +26,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------------
+// clamp to the int8 grid in ONE v_med3_f32: fminf(fmaxf(r, lo), hi) compiles to a canonicalising v_max + v_med3 (the IEEE min/max of
+// a possibly signalling NaN); for a NaN both forms return -128 (v_med3 falls back to min3)
+#ifdef P2V_EXP_NOTRIM   /* A/B baseline builds only (tools/exp): the round-2 forms of the round-3 instruction trims */
+__device__ __forceinline__ float clamp8f(float r) { return fminf(fmaxf(r, -128.f), 127.f); }
+#else
+__device__ __forceinline__ float clamp8f(float r) { return __builtin_amdgcn_fmed3f(r, -128.f, 127.f); }
+#endif
 // clamp(round(v), -128, 127)  == UniformQuantizer.quant for int8 (quantizer/uniform.py:85-87)
-__device__ __forceinline__ int sat8(float v) {
-  float r = rintf(v);
-  r = fminf(fmaxf(r, -128.f), 127.f);
-  return (int)r;
-}
+__device__ __forceinline__ int sat8(float v) { return (int)clamp8f(rintf(v)); }
 __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
   return (unsigned)(a & 255) | ((unsigned)(b & 255) << 8) | ((unsigned)(c & 255) << 16) | ((unsigned)d << 24);
 }
@@ -44,7 +49,7 @@ __device__ __forceinline__ unsigned pack4_sat(float r0, float r1, float r2, floa
   w = __builtin_amdgcn_cvt_pk_u8_f32(r3 + 128.f, 3, w);
   return w ^ 0x80808080u;
 }
-__device__ __forceinline__ float sat8f(float v) { return fminf(fmaxf(rintf(v), -128.f), 127.f); }
+__device__ __forceinline__ float sat8f(float v) { return clamp8f(rintf(v)); }
 
 // Exchange between the two 32-lane halves so that each lane ends with 16 CONTIGUOUS bytes of an MFMA
 // 32x32 accumulator column block.  In: d[g] = bytes [8g+4h, 8g+4h+4) (h = lane>>5).
@@ -117,8 +122,7 @@ __device__ __forceinline__ int gelu_q8(float y, float inv_s, bool force_slow, bo
       r = rintf(gelu_exact(y) * inv_s);
     }
   }
-  r = fminf(fmaxf(r, -128.f), 127.f);
-  return (int)r;
+  return (int)clamp8f(r);
 }
 
 // Four at a time: the fast values are computed branch-free (instruction-level parallelism across the four
@@ -160,7 +164,7 @@ __device__ __forceinline__ unsigned gelu_tab_offset(float y, float k, float off,
 }
 __device__ __forceinline__ int gelu_code_exact(float y, float inv_s) {
   const float r = rintf(gelu_exact(y) * inv_s);
-  return (int)fminf(fmaxf(r, -128.f), 127.f);
+  return (int)clamp8f(r);
 }
 // byte B of d := (y >= thr) ? hi : lo   with e = {thr bits, lo | hi << 8}; the other bytes of d are kept (B > 0) / zeroed (B = 0)
 #define P2V_GELU_SEL(B, UNUSED, DST, YV, ENT)                                                                             \
@@ -262,7 +266,7 @@ __device__ __forceinline__ float div_q8f(float x, float s, float rs) {
   if (__builtin_amdgcn_ballot_w64(slow) != 0) {
     if (slow) r = rintf(x / s);
   }
-  return fminf(fmaxf(r, -128.f), 127.f);
+  return clamp8f(r);
 }
 template <bool CLAMP>
 __device__ __forceinline__ void div_q8fx4(const float (&x)[4], const float (&s)[4], const float (&rs)[4], float (&out)[4]) {
@@ -281,7 +285,7 @@ __device__ __forceinline__ void div_q8fx4(const float (&x)[4], const float (&s)[
       if (!(fabsf(dv[i]) < 0.5f - 1.0e-4f)) r[i] = rintf(x[i] / s[i]);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) out[i] = CLAMP ? fminf(fmaxf(r[i], -128.f), 127.f) : r[i];   // unclamped when the caller packs (saturating)
+  for (int i = 0; i < 4; ++i) out[i] = CLAMP ? clamp8f(r[i]) : r[i];   // unclamped when the caller packs (saturating)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -486,6 +490,14 @@ __device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_
       }
     }
     if (EPI == P2V_EPI_GELU_TAB) {
+#ifdef P2V_EXP_DUMMY   /* experiment only (never in the product build): P2V_EXP_DUMMY independent VALU instructions per 8 outputs */
+      {
+        float dm_ = yy[0][0];
+#pragma unroll
+        for (int q_ = 0; q_ < P2V_EXP_DUMMY; ++q_) asm volatile("v_add_f32 %0, 1.0, %1" : "=v"(dm_) : "v"(yy[0][q_ & 3]));
+        asm volatile("" :: "v"(dm_));
+      }
+#endif
       gelu_tab_q8x8(yy[0], yy[1], gtab, g.ep.gelu.k, g.ep.gelu.off, (float)(g.ep.gelu.cells - 1), d[0][gq], d[1][gq]);
       continue;
     }
@@ -843,6 +855,7 @@ struct LnLane {
   int4 mki[NCH];                      // PTF mask (in_scale / s1)
   float gmin, gmax;                   // extreme |gamma*io| over all channels
   bool pot;                           // 1/out_scale is a power of two for every channel and the fold is exact
+  bool pm_one;                        // post_mul == 1 for every channel (norm1 of P2-ViT: out_scale / channel_scale / qact0 scale): no second requant
 };
 
 // Fold, test and publish the per-channel constants once per workgroup (every thread calls it; contains a barrier), then load this
@@ -851,7 +864,7 @@ template <int NCH, int LANES>
 __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_generic, float* sG, float* sB, float* sP, int* sM,
                                            int tid, int nthreads, LnLane<NCH>& L) {
   const int l32 = tid & (LANES - 1);
-  int potf = force_generic ? 0 : 1;
+  int potf = force_generic ? 0 : 1, pm1 = 1;
   for (int t4 = tid; t4 < NCH * LANES; t4 += nthreads) {   // one thread per 4 channels: fold, test, and publish
     const int c = t4 * 4;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f), b = g, io = make_float4(1.f, 1.f, 1.f, 1.f), pmv = g, mk = g;
@@ -863,6 +876,7 @@ __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_g
       mk = *reinterpret_cast<const float4*>(ln.mask + c);
     }
     const float g4[4] = {g.x, g.y, g.z, g.w}, b4[4] = {b.x, b.y, b.z, b.w}, i4[4] = {io.x, io.y, io.z, io.w};
+    if (c < C) pm1 &= (int)(pmv.x == 1.f) & (int)(pmv.y == 1.f) & (int)(pmv.z == 1.f) & (int)(pmv.w == 1.f);
     float go[4], bo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -882,6 +896,10 @@ __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_g
     *reinterpret_cast<int4*>(sM + c) = make_int4((int)mk.x, (int)mk.y, (int)mk.z, (int)mk.w);
   }
   L.pot = __syncthreads_and(potf) != 0;
+  L.pm_one = __syncthreads_and(pm1) != 0;
+#ifdef P2V_EXP_NOTRIM
+  L.pm_one = false;
+#endif
   // extreme |g io| over all channels (every row group covers all of them)
   float gmin = 3.0e38f, gmax = 0.f;
 #pragma unroll
@@ -950,31 +968,41 @@ __device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane
   // |A| = RN(rs*|g io|) is monotone in |g io|: the two extreme channels bound every channel exactly
   const bool fast = L.pot && rs * L.gmin >= 0x1p-24f && rs * L.gmax < 256.f;
   if (fast) {
+    auto chain = [&](auto PM1c) {
+      constexpr bool PM1 = decltype(PM1c)::value;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const float g4[4] = {L.gm[i].x, L.gm[i].y, L.gm[i].z, L.gm[i].w}, b4[4] = {L.bt[i].x, L.bt[i].y, L.bt[i].z, L.bt[i].w};
-      const float p4[4] = {L.pm[i].x, L.pm[i].y, L.pm[i].z, L.pm[i].w};
-      float q[4];
+      for (int i = 0; i < NCH; ++i) {
+        const float g4[4] = {L.gm[i].x, L.gm[i].y, L.gm[i].z, L.gm[i].w}, b4[4] = {L.bt[i].x, L.bt[i].y, L.bt[i].z, L.bt[i].w};
+        const float p4[4] = {L.pm[i].x, L.pm[i].y, L.pm[i].z, L.pm[i].w};
+        float q[4];
 #pragma unroll
-      for (int j = 0; j < 4; j += 2) {   // two channels at a time: only the 3-source fma is packed (measured on gfx950, tools/ubench/valu_rate:
-        // a wave alone on its SIMD issues a 2-source fp32 op every ~4.9 cycles, a v_pk_mul/add_f32 every ~13, a 3-source v_fma_f32 every ~8, v_pk_fma_f32 ~13)
-        v2f T2, Bq2;
+        for (int j = 0; j < 4; j += 2) {   // two channels at a time: only the 3-source fma is packed (measured on gfx950, tools/ubench/valu_rate:
+          // a wave alone on its SIMD issues a 2-source fp32 op every ~4.9 cycles, a v_pk_mul/add_f32 every ~13, a 3-source v_fma_f32 every ~8, v_pk_fma_f32 ~13)
+          v2f T2, Bq2;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const float A = rs * g4[j + e];
-          const float t = b4[j + e] - mos * g4[j + e];
-          const unsigned Ab = __float_as_uint(A);
-          T2[e] = __uint_as_float(Ab & 0xFFFF0000u);                              // sign * M * 2^-N
-          const int N = 134 - (int)((Ab >> 23) & 255u);                           // in [0, 31] by the range test
-          Bq2[e] = ldexpf(rintf(ldexpf(t, N)), -N);                               // Bv * 2^-N
+          for (int e = 0; e < 2; ++e) {
+            const float A = rs * g4[j + e];
+            const float t = b4[j + e] - mos * g4[j + e];
+            const unsigned Ab = __float_as_uint(A);
+            T2[e] = __uint_as_float(Ab & 0xFFFF0000u);                              // sign * M * 2^-N
+            const int N = 134 - (int)((Ab >> 23) & 255u);                           // in [0, 31] by the range test
+            Bq2[e] = ldexpf(rintf(ldexpf(t, N)), -N);                               // Bv * 2^-N
+          }
+          const v2f x2 = {xq[i][j], xq[i][j + 1]};
+          const v2f o2 = __builtin_elementwise_fma(T2, x2, Bq2);
+          if (PM1) {                                                                // out * 1: the LayerNorm output IS the code
+            q[j] = rintf(o2[0]);
+            q[j + 1] = rintf(o2[1]);
+          } else {
+            q[j] = rintf(rintf(o2[0]) * p4[j]);
+            q[j + 1] = rintf(rintf(o2[1]) * p4[j + 1]);
+          }
         }
-        const v2f x2 = {xq[i][j], xq[i][j + 1]};
-        const v2f o2 = __builtin_elementwise_fma(T2, x2, Bq2);
-        q[j] = rintf(rintf(o2[0]) * p4[j]);
-        q[j + 1] = rintf(rintf(o2[1]) * p4[j + 1]);
+        outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
       }
-      outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
-    }
+    };
+    if (L.pm_one) chain(std::integral_constant<bool, true>{});      // wave-uniform
+    else chain(std::integral_constant<bool, false>{});
   } else {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -1216,6 +1244,308 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
     }
     LG_STAMP(5 + 2 * j);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2c: the fused LayerNorm + GEMM kernel, dense form (round 3).  Same data flow as k_ln_gemm (64 rows per workgroup, LayerNorm
+//   output in an LDS panel, W fragments straight from the fragment-order copy), reorganised around the two facts measured in
+//   round 2 (tools/ubench/valu_rate.hip, profiles/r02_ln_gemm_timeline.txt): a wave alone on its SIMD issues one VALU
+//   instruction per ~4.9 cycles, two waves one per ~2.7; and the matrix pipe sat idle through every epilogue.
+//     * 8 waves (512 threads, one workgroup per CU, up to 256 registers per wave): two waves per SIMD in every phase.  The
+//       LayerNorm phase runs on 16 half waves (4 rows each); in the GEMM phase wave group g = wave >> 2 owns the column tiles
+//       g, g + 2, ..., so both groups stream different W tiles and run the same program half a tile apart.
+//     * software pipeline across column tiles inside a wave: the MFMAs of the group's NEXT tile (second accumulator set) are
+//       issued one at a time between the pieces of the CURRENT tile's epilogue - 24 half-pieces of 4-16 VALU instructions, in
+//       program order, pinned with sched_barrier so hipcc cannot re-cluster them.  An MFMA holds the matrix pipe for 32 cycles
+//       while the wave goes on issuing the epilogue's VALU work: the k-loop disappears under the epilogue.  Three copies of the
+//       tile body: steady state (MFMAs + W prefetch for the tile after), next-to-last (MFMAs only), last (epilogue only).
+//   Results are bit-identical to k_ln_gemm (same ln_prepare / ln_row, same epilogue arithmetic); k_ln_gemm stays for the
+//   arithmetic GELU epilogue (scales without a table) and for launches with activation taps.
+// ---------------------------------------------------------------------------------------------------
+// MFMA q (0 .. 2*NI-1; k-step q>>1, row block q&1) of the next tile goes into half-piece (q*12)/NI of the 24 half-pieces
+template <int NI>
+__host__ __device__ constexpr int lg2_mfma_at(int hp) {
+  for (int q = 0; q < 2 * NI; ++q)
+    if ((q * 12) / NI == hp) return q;
+  return -1;
+}
+
+// EPI: P2V_EPI_REQUANT or P2V_EPI_GELU_TAB;  KT = k-tiles of 64 channels (C <= 64*KT);  NG = wave groups (1: 4 waves, every wave all
+// column tiles, two workgroups per CU; 2: 8 waves, the groups alternate column tiles, one workgroup per CU)
+template <int EPI, int KT, int NG>
+__global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) {
+  constexpr int NT = 256 * NG;           // threads
+  static_assert(EPI == P2V_EPI_REQUANT || EPI == P2V_EPI_GELU_TAB, "pipelined epilogues");
+  constexpr int NCH = (KT + 1) / 2;      // 128-channel groups of a LayerNorm row
+  constexpr int NI = 2 * KT;             // k-steps of 32
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lg_smem[];
+  LG_STAMP(0);
+  const int C = a.C;
+  const int cells = EPI == P2V_EPI_GELU_TAB ? g.ep.gelu.cells : 0;
+  const LnGemmLds lay = ln_gemm_lds(C, g.N, NCH, cells);
+  int8_t* panel = reinterpret_cast<int8_t*>(lg_smem + lay.panel);
+  float* consts = reinterpret_cast<float*>(lg_smem + lay.consts);      // per column tile: colscale[128] | bias[128]
+  const unsigned char* gtab = lg_smem + lay.table;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = NG == 1 ? 0 : (wave >> 2), cw = wave & 3;            // wave group (column-tile parity), 32-column block of a tile
+  const int h = lane >> 5, l31 = lane & 31;
+  const int m0 = blockIdx.x * LG_BM;
+  const int tiles_n = g.tiles_n;
+  const int n_g = (tiles_n - grp + NG - 1) / NG;                       // column tiles of this group: j = grp + NG*it
+
+  // ---- W fragments of the group's first tile (registers): element ((j*4 + cw)*NI + i)*64 + lane of 16 bytes
+  const uint4* wsrc = reinterpret_cast<const uint4*>(g.W) + (long long)cw * NI * 64 + lane;
+  auto wtile = [&](int it) {                                           // fragments of the group's it-th tile (clamped: loads are unconditional)
+    int j = grp + NG * it;
+    j = j < tiles_n ? j : tiles_n - 1;
+    return wsrc + (long long)j * 4 * NI * 64;
+  };
+  v4i wf[NI];
+  {
+    const uint4* w0 = wtile(0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wf[i] = __builtin_bit_cast(v4i, w0[i * 64]);
+  }
+
+  // ---- the 64 rows of the residual stream: one row per half wave, 4 rows each, the second pair in flight while the first is normalised
+  constexpr int RPH = LG_BM / (8 * NG);                                // rows per half wave
+  static_assert(RPH % 2 == 0, "rows are processed in pairs");
+  const int hw = tid >> 5;
+  // 32-bit offsets from the workgroup's first row (64 rows x row stride < 2^31: checked by the launcher): the 64-bit row * stride
+  // products of the first version cost ~20 VALU instructions per row pair
+  const int8_t* xblk = a.x + (long long)m0 * a.row_stride;
+  const int rstride = (int)a.row_stride;
+  const int last_lr = (int)(a.rows - 1 - m0);                           // rows past the end re-read the last row (never stored)
+  auto load_row = [&](int r, unsigned (&w)[NCH]) {
+    int lr = hw * RPH + r;
+    lr = lr < last_lr ? lr : last_lr;
+    const int8_t* rp = xblk + lr * rstride;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (l31 + 32 * i) * 4;
+      w[i] = *reinterpret_cast<const unsigned*>(rp + (c < C ? c : 0));
+    }
+  };
+  unsigned win[2][NCH];
+  load_row(0, win[0]);
+  load_row(1, win[1]);
+  // ---- per-column constants of the whole layer (REQUANT: 2^e folded in, see gemm_stage_epilogue) and the GELU table
+  {
+    const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : 1.0f;
+    for (int n4 = tid; n4 < tiles_n * (GBN / 4); n4 += NT) {           // four columns per thread and turn
+      const int j_ = n4 >> 5, c_ = (n4 & 31) * 4;
+      const float4 cv = *reinterpret_cast<const float4*>(g.colscale + n4 * 4);   // arrays are padded to n_pad
+      const float4 bv = *reinterpret_cast<const float4*>(g.bias + n4 * 4);
+      *reinterpret_cast<float4*>(consts + j_ * 2 * GBN + c_) = make_float4(cv.x * fold, cv.y * fold, cv.z * fold, cv.w * fold);
+      *reinterpret_cast<float4*>(consts + j_ * 2 * GBN + GBN + c_) = make_float4(bv.x * fold, bv.y * fold, bv.z * fold, bv.w * fold);
+    }
+    if (EPI == P2V_EPI_GELU_TAB)
+      for (int i = tid; i < cells; i += NT)
+        reinterpret_cast<uint2*>(lg_smem + lay.table)[i] = reinterpret_cast<const uint2*>(g.ep.gelu.table)[i];
+  }
+  LG_STAMP(1);
+  // ---- LayerNorm -> LDS panel (and, on request, HBM)
+  {
+    float* sG = reinterpret_cast<float*>(lg_smem + lay.fold);
+    float* sB = sG + NCH * 128;
+    float* sP = sB + NCH * 128;
+    int* sM = reinterpret_cast<int*>(sP + NCH * 128);
+    LnLane<NCH> L;
+    ln_prepare<NCH, 32>(a.ln, C, a.force_generic != 0, sG, sB, sP, sM, tid, NT, L);
+    __syncthreads();        // every lane holds its folded constants in registers: the scratch (= the panel) may be overwritten
+#pragma unroll 1
+    for (int r = 0; r < RPH; r += 2) {
+      unsigned wnext[2][NCH];
+      if (r + 2 < RPH) {
+        load_row(r + 2, wnext[0]);
+        load_row(r + 3, wnext[1]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int lrow = hw * RPH + r + u;
+        unsigned wcur[NCH], outw[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) wcur[i] = L.on[i] ? win[u][i] : 0u;
+        ln_row<NCH, 32>(wcur, L, a.ln, C, l31, outw);
+        const long long row = (long long)m0 + lrow;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = (l31 + 32 * i) * 4;
+          if (c < KT * GBK)      // channels past C inside the last k-tile are zero
+            *reinterpret_cast<unsigned*>(panel + (c >> 6) * (LG_BM * GBK) + lrow * GBK + ((((c & 63) >> 4) ^ ((lrow >> 2) & 3)) << 4) + (c & 15)) =
+                L.on[i] ? outw[i] : 0u;
+          if (a.out && L.on[i] && row < a.rows) *reinterpret_cast<unsigned*>(a.out + row * a.out_stride + c) = outw[i];
+        }
+      }
+      if (r + 2 < RPH) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          win[0][i] = wnext[0][i];
+          win[1][i] = wnext[1][i];
+        }
+      }
+    }
+  }
+  LG_STAMP(2);
+  __syncthreads();        // panel, constants and table are complete
+  LG_STAMP(3);
+  if (n_g <= 0) return;   // wave-uniform (a layer with a single column tile: the second group has nothing to do)
+
+  // X fragment addresses: rows l31 / 32+l31 of panel k-tile kt, chunk 2*ks + h
+  const int8_t* pXa = panel + lds_off64(l31, h);
+  const int8_t* pXb = panel + lds_off64(32 + l31, h);
+  const int xks = (lds_off64(l31, 2 + h) - lds_off64(l31, h));           // +-32: the k-step-1 chunk of the same row
+#define LG2_XOFF(i) ((((i) >> 1) * (LG_BM * GBK)) + (((i) & 1) ? xks : 0))
+  v16i acc[2], accn[2];                                                  // current tile (epilogue) / next tile (MFMAs)
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0;
+  // ---- the group's first tile: plain k-loop (nothing to overlap with), W fragments of its second tile requested behind the MFMAs
+  {
+    const uint4* wn = wtile(1);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const v4i xa = *reinterpret_cast<const v4i*>(pXa + LG2_XOFF(i));
+      const v4i xb = *reinterpret_cast<const v4i*>(pXb + LG2_XOFF(i));
+      acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xa, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xb, acc[1], 0, 0, 0);
+      wf[i] = __builtin_bit_cast(v4i, wn[i * 64]);
+    }
+  }
+  LG_STAMP(4);
+  // X fragments of k-step 0 for the first interleaved MFMAs (double-buffered by k-step parity; the panel is the same for every tile)
+  v4i XA[2], XB[2];
+  XA[0] = *reinterpret_cast<const v4i*>(pXa + LG2_XOFF(0));
+  XB[0] = *reinterpret_cast<const v4i*>(pXb + LG2_XOFF(0));
+  XA[1] = XA[0];
+  XB[1] = XB[0];
+  const float gk = g.ep.gelu.k, goff = g.ep.gelu.off, gtmax = (float)(cells - 1);
+
+  // One column tile: the epilogue of acc (tile j) in 24 half-pieces; with MF the 2*NI MFMAs of the group's next tile are issued
+  // one per half-piece into accn (X fragments one k-step ahead); with LD the W fragment of the tile after next replaces the one
+  // an MFMA pair has just consumed.
+  auto tile_body = [&](auto MFc, auto LDc, int j, const uint4* wnn) {
+    constexpr bool MF = decltype(MFc)::value, LD = decltype(LDc)::value;
+    const float* cst = consts + j * 2 * GBN + 32 * cw + 4 * h;           // colscale of this wave's columns; bias at + GBN
+    const int n_tile = j * GBN + 32 * cw;
+    unsigned d[2][4];
+    float4 cs = *reinterpret_cast<const float4*>(cst), bs = *reinterpret_cast<const float4*>(cst + GBN);
+#define LG2_MFMA(HP)                                                                                                     \
+    do {                                                                                                                 \
+      constexpr int q_ = lg2_mfma_at<NI>(HP);                                                                            \
+      if constexpr (MF && q_ >= 0) {                                                                                     \
+        constexpr int i_ = q_ >> 1, nx_ = (i_ + 1) % NI;                                                                 \
+        if constexpr ((q_ & 1) == 0) {                                                                                   \
+          XA[nx_ & 1] = *reinterpret_cast<const v4i*>(pXa + LG2_XOFF(nx_));                                              \
+          if constexpr (i_ == 0) accn[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i_], XA[i_ & 1], (v16i){0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, 0, 0, 0); \
+          else accn[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i_], XA[i_ & 1], accn[0], 0, 0, 0);                    \
+        } else {                                                                                                         \
+          XB[nx_ & 1] = *reinterpret_cast<const v4i*>(pXb + LG2_XOFF(nx_));                                              \
+          if constexpr (i_ == 0) accn[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i_], XB[i_ & 1], (v16i){0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, 0, 0, 0); \
+          else accn[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i_], XB[i_ & 1], accn[1], 0, 0, 0);                    \
+          if constexpr (LD) wf[i_] = __builtin_bit_cast(v4i, wnn[i_ * 64]);                                              \
+        }                                                                                                                \
+      }                                                                                                                  \
+    } while (0)
+#define LG2_FENCE() __builtin_amdgcn_sched_barrier(0)
+    auto group = [&](auto GQc) {
+      constexpr int gq = decltype(GQc)::value;
+      const float4 csc = cs, bsc = bs;
+      if (gq < 3) {                                                      // constants of the next group: an LDS round trip ahead
+        cs = *reinterpret_cast<const float4*>(cst + 8 * (gq + 1));
+        bs = *reinterpret_cast<const float4*>(cst + GBN + 8 * (gq + 1));
+      }
+      float y0[4], y1[4];
+      // F.linear on fake-quantised operands: exact integer sum * (s_x*s_w[n]), then ONE rounding for the fp32 bias (layers.py:178)
+      LG2_MFMA(6 * gq + 0);
+      y0[0] = __builtin_fmaf((float)acc[0][4 * gq + 0], csc.x, bsc.x);
+      y0[1] = __builtin_fmaf((float)acc[0][4 * gq + 1], csc.y, bsc.y);
+      y0[2] = __builtin_fmaf((float)acc[0][4 * gq + 2], csc.z, bsc.z);
+      y0[3] = __builtin_fmaf((float)acc[0][4 * gq + 3], csc.w, bsc.w);
+      LG2_FENCE();
+      LG2_MFMA(6 * gq + 1);
+      y1[0] = __builtin_fmaf((float)acc[1][4 * gq + 0], csc.x, bsc.x);
+      y1[1] = __builtin_fmaf((float)acc[1][4 * gq + 1], csc.y, bsc.y);
+      y1[2] = __builtin_fmaf((float)acc[1][4 * gq + 2], csc.z, bsc.z);
+      y1[3] = __builtin_fmaf((float)acc[1][4 * gq + 3], csc.w, bsc.w);
+      LG2_FENCE();
+      if constexpr (EPI == P2V_EPI_GELU_TAB) {
+        uint2 e0[4], e1[4];
+        LG2_MFMA(6 * gq + 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e0[i] = *reinterpret_cast<const uint2*>(gtab + gelu_tab_offset(y0[i], gk, goff, gtmax));
+        LG2_FENCE();
+        LG2_MFMA(6 * gq + 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e1[i] = *reinterpret_cast<const uint2*>(gtab + gelu_tab_offset(y1[i], gk, goff, gtmax));
+        LG2_FENCE();
+        LG2_MFMA(6 * gq + 4);
+        d[0][gq] = 0;
+        P2V_GELU_SEL(0, "UNUSED_PAD", d[0][gq], y0[0], e0[0]);
+        P2V_GELU_SEL(1, "UNUSED_PRESERVE", d[0][gq], y0[1], e0[1]);
+        P2V_GELU_SEL(2, "UNUSED_PRESERVE", d[0][gq], y0[2], e0[2]);
+        P2V_GELU_SEL(3, "UNUSED_PRESERVE", d[0][gq], y0[3], e0[3]);
+        LG2_FENCE();
+        LG2_MFMA(6 * gq + 5);
+        d[1][gq] = 0;
+        P2V_GELU_SEL(0, "UNUSED_PAD", d[1][gq], y1[0], e1[0]);
+        P2V_GELU_SEL(1, "UNUSED_PRESERVE", d[1][gq], y1[1], e1[1]);
+        P2V_GELU_SEL(2, "UNUSED_PRESERVE", d[1][gq], y1[2], e1[2]);
+        P2V_GELU_SEL(3, "UNUSED_PRESERVE", d[1][gq], y1[3], e1[3]);
+        LG2_FENCE();
+      } else {       // REQUANT: the 2^e of the following QAct is folded into the constants; the byte packing saturates
+        float r0[4], r1[4];
+        LG2_MFMA(6 * gq + 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r0[i] = rintf(y0[i]);
+        LG2_FENCE();
+        LG2_MFMA(6 * gq + 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r1[i] = rintf(y1[i]);
+        LG2_FENCE();
+        LG2_MFMA(6 * gq + 4);
+        d[0][gq] = pack4_sat(r0[0], r0[1], r0[2], r0[3]);
+        LG2_FENCE();
+        LG2_MFMA(6 * gq + 5);
+        d[1][gq] = pack4_sat(r1[0], r1[1], r1[2], r1[3]);
+        LG2_FENCE();
+      }
+    };
+    group(std::integral_constant<int, 0>{});
+    group(std::integral_constant<int, 1>{});
+    group(std::integral_constant<int, 2>{});
+    group(std::integral_constant<int, 3>{});
+#undef LG2_MFMA
+#undef LG2_FENCE
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const uint4 o = halves_to_row16(d[b][0], d[b][1], d[b][2], d[b][3]);
+      const int m = m0 + 32 * b + l31;
+      if (m < g.M && n_tile + 16 * h < g.N)
+        *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)m * g.ldo + n_tile + 16 * h) = o;
+    }
+    if constexpr (MF) {
+      acc[0] = accn[0];
+      acc[1] = accn[1];
+    }
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  int it = 0;
+  for (; it + 2 < n_g; ++it) {
+    tile_body(T_{}, T_{}, grp + NG * it, wtile(it + 2));
+    LG_STAMP(5 + it);
+  }
+  if (it + 1 < n_g) {
+    tile_body(T_{}, F_{}, grp + NG * it, wsrc);
+    LG_STAMP(5 + it);
+    ++it;
+  }
+  tile_body(F_{}, F_{}, grp + NG * it, wsrc);
+  LG_STAMP(5 + it);
+#undef LG2_XOFF
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1857,25 +2187,34 @@ bool p2v_ln_gemm_supported(int epi, int C, int N, int table_cells) {
   if (C % 4 || C > 384 || N % 16) return false;
   return ln_gemm_lds(C, N, ((C + GBK - 1) / GBK + 1) / 2, table_cells).total <= 80 * 1024;     // two workgroups per CU
 }
-template <int EPI, int KT>
+template <int EPI, int KT, int VER>
 static int launch_ln_gemm_t(const LnArgs& a, const GemmArgs& g, int cells, hipStream_t st) {
   const int smem = ln_gemm_lds(a.C, g.N, (KT + 1) / 2, cells).total;
   static int granted[16] = {0};                 // per device: the dynamic LDS size this instantiation has been allowed so far
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+  const void* fn;
+  if constexpr (VER == 3) fn = reinterpret_cast<const void*>(&k_ln_gemm2<EPI, KT, 2>);
+  else if constexpr (VER == 2) fn = reinterpret_cast<const void*>(&k_ln_gemm2<EPI, KT, 1>);
+  else fn = reinterpret_cast<const void*>(&k_ln_gemm<EPI, KT>);
   if (dev < 0 || smem > granted[dev]) {         // (a racing second thread only repeats the call)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_gemm<EPI, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     if (dev >= 0) granted[dev] = smem;
   }
-  hipLaunchKernelGGL((k_ln_gemm<EPI, KT>), dim3((unsigned)((g.M + LG_BM - 1) / LG_BM)), dim3(256), (unsigned)smem, st, a, g);
+  const dim3 grid((unsigned)((g.M + LG_BM - 1) / LG_BM));
+  if constexpr (VER == 3) hipLaunchKernelGGL((k_ln_gemm2<EPI, KT, 2>), grid, dim3(512), (unsigned)smem, st, a, g);
+  else if constexpr (VER == 2) hipLaunchKernelGGL((k_ln_gemm2<EPI, KT, 1>), grid, dim3(256), (unsigned)smem, st, a, g);
+  else hipLaunchKernelGGL((k_ln_gemm<EPI, KT>), grid, dim3(256), (unsigned)smem, st, a, g);
   CHECK_LAUNCH();
   return 0;
 }
+int g_ln_gemm_ver = 2;    // P2V_LN_GEMM_V=1: the 4-wave kernel of round 2 for every launch (A/B runs; same results)
 // g0.W must point to the FRAGMENT-ORDER copy of the weights (p2v_linear.w_frag)
 int p2v_launch_ln_gemm(int epi, const LnArgs& a_, const GemmArgs& g0, hipStream_t st) {
   const int cells = (epi == P2V_EPI_GELU && g0.ep.gelu.table) ? g0.ep.gelu.cells : 0;
   if (!p2v_ln_gemm_supported(epi, a_.C, g0.N, cells)) return -3;
+  if (a_.row_stride < 0 || a_.row_stride > (1 << 24)) return -3;       // the kernels address a workgroup's 64 rows with 32-bit offsets
   LnArgs a = a_;
   a.force_generic = g_ln_generic;
   GemmArgs g = g0;
@@ -1884,18 +2223,27 @@ int p2v_launch_ln_gemm(int epi, const LnArgs& a_, const GemmArgs& g0, hipStream_
   g.stamps = g_gemm_stamps;
 #endif
   const int kt = (a.C + GBK - 1) / GBK;
-#define P2V_LG(EPI_)                                                              \
+#define P2V_LG(EPI_, VER_)                                                        \
   switch (kt) {                                                                   \
-    case 1: return launch_ln_gemm_t<EPI_, 1>(a, g, cells, st);                    \
-    case 2: return launch_ln_gemm_t<EPI_, 2>(a, g, cells, st);                    \
-    case 3: return launch_ln_gemm_t<EPI_, 3>(a, g, cells, st);                    \
-    case 4: return launch_ln_gemm_t<EPI_, 4>(a, g, cells, st);                    \
-    case 5: return launch_ln_gemm_t<EPI_, 5>(a, g, cells, st);                    \
-    default: return launch_ln_gemm_t<EPI_, 6>(a, g, cells, st);                   \
+    case 1: return launch_ln_gemm_t<EPI_, 1, VER_>(a, g, cells, st);              \
+    case 2: return launch_ln_gemm_t<EPI_, 2, VER_>(a, g, cells, st);              \
+    case 3: return launch_ln_gemm_t<EPI_, 3, VER_>(a, g, cells, st);              \
+    case 4: return launch_ln_gemm_t<EPI_, 4, VER_>(a, g, cells, st);              \
+    case 5: return launch_ln_gemm_t<EPI_, 5, VER_>(a, g, cells, st);              \
+    default: return launch_ln_gemm_t<EPI_, 6, VER_>(a, g, cells, st);             \
   }
-  if (epi == P2V_EPI_REQUANT) { P2V_LG(P2V_EPI_REQUANT) }
-  if (cells) { P2V_LG(P2V_EPI_GELU_TAB) }
-  P2V_LG(P2V_EPI_GELU)
+  // the dense 8-wave kernel: REQUANT and table GELU without activation taps; everything else runs the 4-wave kernel
+  if (g_ln_gemm_ver == 3 && !g.ep.tap_out) {
+    if (epi == P2V_EPI_REQUANT) { P2V_LG(P2V_EPI_REQUANT, 3) }
+    if (cells) { P2V_LG(P2V_EPI_GELU_TAB, 3) }
+  }
+  if (g_ln_gemm_ver == 2 && !g.ep.tap_out) {
+    if (epi == P2V_EPI_REQUANT) { P2V_LG(P2V_EPI_REQUANT, 2) }
+    if (cells) { P2V_LG(P2V_EPI_GELU_TAB, 2) }
+  }
+  if (epi == P2V_EPI_REQUANT) { P2V_LG(P2V_EPI_REQUANT, 1) }
+  if (cells) { P2V_LG(P2V_EPI_GELU_TAB, 1) }
+  P2V_LG(P2V_EPI_GELU, 1)
 #undef P2V_LG
 }
 

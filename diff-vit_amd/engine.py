@@ -106,12 +106,15 @@ def lib():
     L.p2v_forward_taps.argtypes = [_p, _p, _i, C.POINTER(C.c_int8), _i, _p, _p, C.c_size_t, C.POINTER(_p), C.POINTER(_p), _p]
     L.p2v_forward_profile.argtypes = [_p, _p, _i, C.POINTER(C.c_int8), _i, _p, _p, C.c_size_t, _p, C.POINTER(C.c_float),
                                       C.POINTER(C.c_int32), _i]
+    L.p2v_forward_profile_begin.argtypes = [_p, _p, _i, C.POINTER(C.c_int8), _i, _p, _p, C.c_size_t, _p, C.POINTER(_p)]
+    L.p2v_forward_profile_end.argtypes = [_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), _i]
     L.p2v_quantize_patchify.argtypes = [_p, _i, _i, _i, _i, _i, _f, _p, _i, _p]
     L.p2v_gemm_i8.argtypes = [_i, _p, _i, _i, _i, _i, C.POINTER(Linear), C.POINTER(Epilogue), _p, _i, _p, _p]
     L.p2v_int_layernorm.argtypes = [_p, _ll, _i, _i, C.POINTER(Ln), _p, _ll, _p]
     L.p2v_lis_attention.argtypes = [_p, _i, _i, _i, _i, C.POINTER(Attn), _p, _p, _p]
     L.p2v_ln_gemm_i8.argtypes = [_i, _p, _ll, _i, _i, C.POINTER(Ln), _i, C.POINTER(Linear), C.POINTER(Epilogue), _p, _i, _p, _p]
     L.p2v_ln_gemm_fusable.argtypes = [_i, _i, _i, _i]
+    L.p2v_set_tuning.argtypes = [C.c_char_p, _i]
     L.p2v_ln_gemm_fusable.restype = _i
     L.p2v_run_ops.argtypes = [C.POINTER(Op), _i, _p]
     L.p2v_run_ops_profile.argtypes = [C.POINTER(Op), _i, _p, C.POINTER(C.c_float)]

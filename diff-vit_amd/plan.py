@@ -285,36 +285,52 @@ class FrozenPlan:
                 taps['qkv_output'], taps['fc1_output'] = qkv, fc1
         return out
 
-    def forward_streams(self, images, bit_config, out, n_streams=3):
-        """Same result as ``forward``; the batch is cut into ``n_streams`` contiguous slices that run on their own HIP
-        streams with their own workspaces.  Images are independent, so this is only a scheduling choice: kernels of one
-        slice (e.g. a VALU-bound GELU epilogue) overlap latency- or MFMA-bound phases of another slice's kernels."""
+    def slice_sizes(self, batch, n_streams=3):
+        """Batch slices of ``forward_streams``: a balanced contiguous split (256 -> 86 + 85 + 85).  Measured in round 3
+        (profiles/r03_slicing.txt): slices cut to one fused-kernel workgroup per CU (83 + 83 + 83 + 7), two slices of 128 or uneven
+        splits all give the same step time within 1 % -- the step runs at the board's power limit, not at a scheduling limit."""
+        if n_streams <= 1 or batch < 2 * n_streams:
+            return [batch]
+        q, r = divmod(batch, n_streams)
+        return [q + (1 if i < r else 0) for i in range(n_streams)]
+
+    def forward_streams(self, images, bit_config, out, n_streams=3, slices=None):
+        """Same result as ``forward``; the batch is cut into contiguous slices (``slice_sizes`` or an explicit list) that run on
+        their own HIP streams with their own workspaces (a slice beyond ``n_streams`` runs on the caller's stream).  Images are
+        independent, so this is only a scheduling choice: kernels of one slice (e.g. a VALU-bound GELU epilogue) overlap latency-
+        or MFMA-bound phases of another slice's kernels."""
         images, cfg = self._check(images, bit_config)
         B = images.shape[0]
-        if n_streams <= 1 or B < 2 * n_streams:
+        sizes = list(slices) if slices is not None else self.slice_sizes(B, n_streams)
+        if sum(sizes) != B or min(sizes) < 1:
+            raise AssertionError('slices %r do not cover a batch of %d' % (sizes, B))
+        if len(sizes) == 1:
             return self.forward(images, bit_config, out=out)
         if tuple(out.shape) != (B, self.arch['num_classes']) or out.device != self.device or out.dtype != torch.float32 or not out.is_contiguous():
             raise AssertionError('out must be a contiguous fp32 [%d, %d] tensor on %s' % (B, self.arch['num_classes'], self.device))
         with torch.cuda.device(self.device):
-            if getattr(self, '_streams', None) is None or len(self._streams) != n_streams:
-                self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
-                self._ws_multi = [None] * n_streams
+            n_side = min(len(sizes), max(n_streams, 1))
+            if getattr(self, '_streams', None) is None or len(self._streams) < n_side:
+                self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_side)]
+            if getattr(self, '_ws_multi', None) is None or len(self._ws_multi) < len(sizes):
+                self._ws_multi = (getattr(self, '_ws_multi', None) or []) + [None] * (len(sizes) - len(getattr(self, '_ws_multi', None) or []))
             cur = torch.cuda.current_stream(self.device)
             L = E.lib()
-            q, r = divmod(B, n_streams)          # balanced split: 256 -> 86 + 85 + 85 (an 85-image slice is 510 attention workgroups,
-            lo = hi = 0                          # just under the 512 that are resident at once; 86 images need a second round)
-            for i, st in enumerate(self._streams):
-                lo, hi = hi, hi + q + (1 if i < r else 0)
-                if lo >= hi:
-                    break
-                n = L.p2v_workspace_bytes(self._handle, hi - lo)
+            used = []
+            lo = hi = 0
+            for i, n_i in enumerate(sizes):
+                lo, hi = hi, hi + n_i
+                st = self._streams[i] if i < n_side else cur        # slices beyond the side streams: the caller's stream
+                n = L.p2v_workspace_bytes(self._handle, n_i)
                 if self._ws_multi[i] is None or self._ws_multi[i].numel() < n:
                     self._ws_multi[i] = torch.empty(n, dtype=torch.uint8, device=self.device)
-                st.wait_stream(cur)
+                if st is not cur:
+                    st.wait_stream(cur)
+                    used.append(st)
                 xi, oi = images[lo:hi], out[lo:hi]
-                E.check(L.p2v_forward(self._handle, E.ptr(xi), hi - lo, cfg, len(bit_config), E.ptr(oi), E.ptr(self._ws_multi[i]),
+                E.check(L.p2v_forward(self._handle, E.ptr(xi), n_i, cfg, len(bit_config), E.ptr(oi), E.ptr(self._ws_multi[i]),
                                       self._ws_multi[i].numel(), -1, C.c_void_p(st.cuda_stream)))
-            for st in self._streams:
+            for st in used:
                 cur.wait_stream(st)
         return out
 
@@ -333,6 +349,47 @@ class FrozenPlan:
         if n < 0:
             E.check(n)
         return [(E.KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(n)]
+
+    def profile_streams(self, images, bit_config, n_streams=3, slices=None, rounds=3):
+        """per-launch times UNDER OVERLAP: the slices of ``forward_streams`` run concurrently on their streams, each with HIP events
+        between its launches (``p2v_forward_profile_begin`` / ``_end``); ``rounds`` consecutive steps are enqueued back to back so that
+        the middle one runs in the steady state.  Returns (per-slice list of [(kind_name, ms), ...] of the middle round, wall ms of it)."""
+        images, cfg = self._check(images, bit_config)
+        B = images.shape[0]
+        sizes = list(slices) if slices is not None else self.slice_sizes(B, n_streams)
+        out = torch.empty(B, self.arch['num_classes'], dtype=torch.float32, device=self.device)
+        L = E.lib()
+        n_max = 7 * self.depth + 8
+        with torch.cuda.device(self.device):
+            self.forward_streams(images, bit_config, out, n_streams, sizes)          # streams and workspaces exist
+            torch.cuda.synchronize(self.device)
+            cur = torch.cuda.current_stream(self.device)
+            n_side = min(len(sizes), max(n_streams, 1))
+            tokens = []
+            for r in range(rounds):
+                lo = hi = 0
+                row = []
+                for i, n_i in enumerate(sizes):
+                    lo, hi = hi, hi + n_i
+                    st = self._streams[i] if i < n_side else cur
+                    tok = C.c_void_p()
+                    E.check(L.p2v_forward_profile_begin(self._handle, E.ptr(images[lo:hi]), n_i, cfg, len(bit_config), E.ptr(out[lo:hi]),
+                                                        E.ptr(self._ws_multi[i]), self._ws_multi[i].numel(), C.c_void_p(st.cuda_stream), C.byref(tok)))
+                    row.append(tok)
+                tokens.append(row)
+            res = []
+            for r, row in enumerate(tokens):
+                per = []
+                for tok in row:
+                    ms = (C.c_float * n_max)()
+                    kind = (C.c_int32 * n_max)()
+                    n = L.p2v_forward_profile_end(tok, ms, kind, n_max)
+                    if n < 0:
+                        E.check(n)
+                    per.append([(E.KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(n)])
+                res.append(per)
+        mid = res[len(res) // 2]
+        return mid, max(sum(ms for _, ms in per) for per in mid)
 
     def view(self, batch, name, rows, cols):
         """int8 view of a workspace activation buffer (parity tests)."""

@@ -210,6 +210,14 @@ int p2v_forward_profile(p2v_plan* plan, const float* images, int batch, const in
                         float* logits, void* workspace, size_t workspace_bytes, void* stream, float* ms_out,
                         int32_t* kind_out, int max_launches);
 
+/* The same measurement for forwards that run CONCURRENTLY on several streams (the batch slices of the default step): _begin enqueues
+ * the forward with its events on `stream` and returns at once with a token; _end synchronises on that forward's last event, fills
+ * ms_out / kind_out like p2v_forward_profile, frees the token and returns the number of launches.  Begin every slice first, then end
+ * them: ms_out[i] is then the duration of launch i WHILE the other streams' kernels run. */
+int p2v_forward_profile_begin(p2v_plan* plan, const float* images, int batch, const int8_t* bit_config, int n_cfg,
+                              float* logits, void* workspace, size_t workspace_bytes, void* stream, void** token);
+int p2v_forward_profile_end(void* token, float* ms_out, int32_t* kind_out, int max_launches);
+
 /* byte offsets of the named activation buffers inside the workspace for `batch` ("patches", "x", "ln",
  * "qkv", "att", "hid", "cls"); returns <0 for unknown names. */
 long long p2v_workspace_view(const p2v_plan* plan, int batch, const char* name);
@@ -348,6 +356,13 @@ int p2v_gelu_err_sweep(unsigned first_bits, unsigned count, float* max_err, void
 
 const char* p2v_last_error(void);
 int p2v_abi_version(void);
+
+/* Scheduling / A-B switches of the process (also read once from the environment: P2V_LN_GEMM, P2V_LN_GEMM_V, P2V_LN_GENERIC,
+ * P2V_LN_ROWS, P2V_ATTN_WAVES, P2V_GEMM_STAGES).  None of them changes a result - every variant is bit-identical and is driven
+ * through this call by the parity tests:
+ *   "ln_gemm" 0/1 (fuse LayerNorm into qkv / fc1), "ln_gemm_version" 1/2 (4-wave / 8-wave pipelined fused kernel),
+ *   "ln_generic" 0/1 (generic LayerNorm chain), "ln_rows" 1..64, "attn_waves" 4..8, "gemm_stages" 2/3. */
+int p2v_set_tuning(const char* name, int value);
 
 #ifdef __cplusplus
 }

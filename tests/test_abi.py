@@ -112,6 +112,19 @@ def test_module_cache_follows_replaced_submodules():
     assert m.blocks[0].attn.proj.calibrate
 
 
+def test_tuning_switches():
+    """p2v_set_tuning: known switches with values in range are accepted, everything else is an argument error."""
+    import diff_vit_amd
+    E = diff_vit_amd.engine
+    L = E.lib()
+    for name, good, bad in ((b'ln_gemm_version', 3, 4), (b'ln_rows', 4, 0), (b'attn_waves', 8, 9), (b'gemm_stages', 3, 5)):
+        assert L.p2v_set_tuning(name, good) == 0
+        assert L.p2v_set_tuning(name, bad) == E.E_ARG
+    assert L.p2v_set_tuning(b'ln_gemm_version', 2) == 0 and L.p2v_set_tuning(b'ln_gemm', 1) == 0 and L.p2v_set_tuning(b'ln_generic', 0) == 0
+    assert L.p2v_set_tuning(b'no_such_switch', 1) == E.E_ARG and L.p2v_set_tuning(None, 1) == E.E_ARG
+    assert b'unknown switch' in L.p2v_last_error() or b'null name' in L.p2v_last_error()
+
+
 def test_custom_ops_registered_and_gpu_only():
     """torch.ops.p2vit.* exist after import and have no CPU kernel (no silent fallback)."""
     import torch

@@ -165,7 +165,7 @@ def test_deit_small_full_batch_properties(dva, oracle, synth):
     one = plan.forward(x, bits).cpu()
     assert torch.equal(one, o)                                      # one stream == two streams
     out3 = torch.empty(256, 1000, device='cuda')
-    plan.forward_streams(x, bits, out3)                             # the default: three slices (86 + 86 + 84 images)
+    plan.forward_streams(x, bits, out3)                             # the default: three balanced slices (86 + 85 + 85 images)
     assert torch.equal(out3.cpu(), o)
     assert torch.equal(plan.forward(x[:255], bits).cpu(), o[:255])
     assert len(set(o[:32].argmax(1).tolist())) > 3
@@ -368,7 +368,19 @@ def test_ln_gemm_fused_vs_separate_and_oracle(dva, oracle, C_, N, M, kind, table
     E.check(L.p2v_int_layernorm(E.ptr(d[0]), C_, M, C_, C.byref(lnp), E.ptr(ln_sep), k_pad, E.stream_ptr()))
     out_sep = torch.zeros(M, N, dtype=torch.int8, device='cuda')
     E.check(L.p2v_gemm_i8(ek, E.ptr(ln_sep), k_pad, M, k_pad, N, C.byref(lin), C.byref(epi), E.ptr(out_sep), N, None, E.stream_ptr()))
-    # fused
+    # fused: every kernel version the tuning switch selects (1: the 4-wave kernel of round 2; 2 / 3: the pipelined kernel with 4 / 8
+    # waves; the arithmetic-GELU launches of versions 2 / 3 run the version-1 kernel) must give the same bytes
+    try:
+        for ver in (1, 3, 2):
+            E.check(L.p2v_set_tuning(b'ln_gemm_version', ver))
+            ln_v = torch.full((M, C_), 99, dtype=torch.int8, device='cuda')
+            out_v = torch.full((M, N), 77, dtype=torch.int8, device='cuda')
+            E.check(L.p2v_ln_gemm_i8(ek, E.ptr(d[0]), C_, M, C_, C.byref(lnp), N, C.byref(lin), C.byref(epi), E.ptr(out_v), N, E.ptr(ln_v), E.stream_ptr()))
+            torch.cuda.synchronize()
+            assert torch.equal(ln_v, ln_sep[:, :C_]), ver
+            assert torch.equal(out_v, out_sep), (ver, int((out_v != out_sep).sum()))
+    finally:
+        E.check(L.p2v_set_tuning(b'ln_gemm_version', 2))
     ln_f = torch.full((M, C_), 99, dtype=torch.int8, device='cuda')
     out_f = torch.full((M, N), 77, dtype=torch.int8, device='cuda')
     E.check(L.p2v_ln_gemm_i8(ek, E.ptr(d[0]), C_, M, C_, C.byref(lnp), N, C.byref(lin), C.byref(epi), E.ptr(out_f), N, E.ptr(ln_f), E.stream_ptr()))

@@ -1,5 +1,7 @@
 """GPU diagnostic (diag build: make -C diff-vit_amd/csrc diag): per-workgroup phase stamps of one fused LayerNorm+GEMM launch.
-usage: python tools/ln_gemm_timeline.py [N=1536] [kind=1 (GELU) | 0 (REQUANT)] [images=128]"""
+usage: python tools/ln_gemm_timeline.py [N=1536] [kind=1 (GELU) | 0 (REQUANT)] [images=83] [version=2]
+(version 1 = the 4-wave kernel: stamps 4+2j / 5+2j after the k-loop / epilogue of column tile j; version 2 / 3 = the pipelined
+kernel with 4 / 8 waves, wave 0 of group 0: stamp 4 after the first k-loop, 5+it after the it-th tile body)"""
 import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -10,7 +12,9 @@ L = E.lib()
 L.p2v_debug_set_gemm_stamps.argtypes = [C.c_void_p]; L.p2v_debug_set_gemm_stamps.restype = None
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1536
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else E.EPI_GELU
-M, Cc = (int(sys.argv[3]) if len(sys.argv) > 3 else 128) * 197, 384
+M, Cc = (int(sys.argv[3]) if len(sys.argv) > 3 else 83) * 197, 384
+ver = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+E.check(L.p2v_set_tuning(b'ln_gemm_version', ver))
 x = torch.randint(-128, 128, (M, Cc), dtype=torch.int8, device='cuda')
 w = torch.randint(-128, 128, (N, Cc), dtype=torch.int8, device='cuda')
 cs = torch.full((N,), 2.0 ** -12, device='cuda'); b = torch.randn(N, device='cuda')
@@ -32,13 +36,20 @@ L.p2v_debug_set_gemm_stamps(None)
 s = st.cpu().numpy().reshape(nblk, 64).astype(np.int64)
 tn = (N + 127) // 128
 t0 = s[:, 0].min()
-end = s[:, 5 + 2 * (tn - 1)]
-print('blocks', nblk, 'column tiles', tn, 'kernel span (ticks)', (end - t0).max())
 ph = lambda a_, b_: np.percentile(s[:, b_] - s[:, a_], [5, 50, 95]).astype(int)
-print('issue W + constants', ph(0, 1), ' LayerNorm', ph(1, 2), ' barrier', ph(2, 3))
-kl = np.stack([s[:, 4 + 2 * j] - (s[:, 3] if j == 0 else s[:, 3 + 2 * j]) for j in range(tn)], 1)
-ep = np.stack([s[:, 5 + 2 * j] - s[:, 4 + 2 * j] for j in range(tn)], 1)
-print('k-loop per column tile (median over blocks):', np.median(kl, 0).astype(int))
-print('epilogue per column tile (median):          ', np.median(ep, 0).astype(int))
+if ver == 1:
+    end = s[:, 5 + 2 * (tn - 1)]
+    print('version 1  blocks', nblk, 'column tiles', tn, 'kernel span (ticks)', (end - t0).max())
+    print('issue W + constants', ph(0, 1), ' LayerNorm', ph(1, 2), ' barrier', ph(2, 3))
+    kl = np.stack([s[:, 4 + 2 * j] - (s[:, 3] if j == 0 else s[:, 3 + 2 * j]) for j in range(tn)], 1)
+    ep = np.stack([s[:, 5 + 2 * j] - s[:, 4 + 2 * j] for j in range(tn)], 1)
+    print('k-loop per column tile (median over blocks):', np.median(kl, 0).astype(int))
+    print('epilogue per column tile (median):          ', np.median(ep, 0).astype(int))
+else:
+    ng = tn if ver == 2 else (tn + 1) // 2      # tiles of wave group 0 (version 2: one group; 3: two groups)
+    end = s[:, 5 + ng - 1]
+    print('version', ver, ' blocks', nblk, 'column tiles', tn, '(group 0:', ng, ') kernel span (ticks)', (end - t0).max())
+    print('issue W + constants', ph(0, 1), ' LayerNorm', ph(1, 2), ' barrier', ph(2, 3), ' first k-loop', ph(3, 4))
+    tb = np.stack([s[:, 5 + i] - s[:, 4 + i] for i in range(ng)], 1)
+    print('tile bodies of group 0 (median over blocks):', np.median(tb, 0).astype(int))
 print('total per block', np.percentile(end - s[:, 0], [5, 50, 95]).astype(int), ' start spread', np.percentile(s[:, 0] - t0, [50, 95, 100]).astype(int))
-
