@@ -90,6 +90,7 @@ extern int g_attn_waves;
 extern int g_gemm_stages;
 extern int g_ln_gemm;
 extern int g_ln_gemm_ver;
+extern int g_gemm_tile;
 // Tuning / A-B switches read once per process (first plan or first version query).  None of them changes results:
 // P2V_LN_GENERIC forces the generic LayerNorm chain (bit-identical to the fast one, both are tested).
 static void read_env_once() {
@@ -104,6 +105,8 @@ static void read_env_once() {
   if (e) g_ln_gemm = atoi(e) != 0;
   e = getenv("P2V_LN_GEMM_V");
   if (e && atoi(e) >= 1 && atoi(e) <= 3) g_ln_gemm_ver = atoi(e);
+  e = getenv("P2V_GEMM_TILE");
+  if (e && (atoi(e) == 0 || atoi(e) == 128 || atoi(e) == 256)) g_gemm_tile = atoi(e);
   e = getenv("P2V_LN_ROWS");
   if (e && atoi(e) >= 1 && atoi(e) <= 64) g_ln_rows = atoi(e);
   e = getenv("P2V_LN_GENERIC");
@@ -120,6 +123,7 @@ int p2v_set_tuning(const char* name, int value) {
   if (!strcmp(name, "ln_rows") && value >= 1 && value <= 64) { g_ln_rows = value; return P2V_OK; }
   if (!strcmp(name, "attn_waves") && value >= 4 && value <= 8) { g_attn_waves = value; return P2V_OK; }
   if (!strcmp(name, "gemm_stages") && (value == 2 || value == 3)) { g_gemm_stages = value; return P2V_OK; }
+  if (!strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) { g_gemm_tile = value; return P2V_OK; }
   return fail(P2V_E_ARG, "p2v_set_tuning: unknown switch or value out of range: %s = %d", name, value);
 }
 const char* p2v_last_error(void) { return g_err; }

@@ -436,7 +436,9 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
 // The same epilogue for the TWO 32-row blocks a wave owns under one 32-column group (rows m_first + l31 and m_first + 32 + l31): the
 // per-channel constants depend on the columns only, so they are read from LDS once per 4-channel group and used for both blocks
 // (half the LDS reads and half the exposed read latencies of two gemm_epilogue_tile calls).  REQUANT / GELU / GELU_TAB / RESID.
-template <int EPI>
+// LEAN: no look-ahead of the per-channel constants (24 registers in the RESID form): the 8-wave 256-row tile must stay within 128
+// VGPRs and has four waves per SIMD to cover the LDS round trip instead
+template <int EPI, bool LEAN = false>
 __device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_first, int n_tile, int nl, int h, const GemmArgs& g,
                                                     const EpiLds* e, const uint4 (&resv)[2], const unsigned char* gtab = nullptr) {
   static_assert(EPI == P2V_EPI_REQUANT || EPI == P2V_EPI_GELU || EPI == P2V_EPI_GELU_TAB || EPI == P2V_EPI_RESID, "row-pair epilogue");
@@ -456,16 +458,18 @@ __device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_
     if (EPI == P2V_EPI_RESID) {
       k.sm = *reinterpret_cast<const float4*>(e->s_mid + c); k.sr = *reinterpret_cast<const float4*>(e->s_res + c);
       k.sn = *reinterpret_cast<const float4*>(e->s_next + c); k.rm = *reinterpret_cast<const float4*>(e->r_mid + c);
-      k.rn = *reinterpret_cast<const float4*>(e->r_next + c); k.mr = *reinterpret_cast<const float4*>(e->m128_sres + c);
+      k.rn = *reinterpret_cast<const float4*>(e->r_next + c);
+      if (!LEAN) k.mr = *reinterpret_cast<const float4*>(e->m128_sres + c);
     }
     return k;
   };
-  Consts knext = load_consts(0);
+  Consts knext;
+  if (!LEAN) knext = load_consts(0);
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
     const int n = n_tile + 8 * gq + 4 * h;
-    const Consts k = knext;
-    if (gq < 3) knext = load_consts(gq + 1);
+    const Consts k = LEAN ? load_consts(gq) : knext;
+    if (!LEAN && gq < 3) knext = load_consts(gq + 1);
     const float4 cs = k.cs, bs = k.bs;
     float smv[4], srv[4], snv[4], rmv[4], rnv[4], mrv[4];
     if (EPI == P2V_EPI_RESID) {
@@ -474,7 +478,12 @@ __device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_
       snv[0] = k.sn.x; snv[1] = k.sn.y; snv[2] = k.sn.z; snv[3] = k.sn.w;
       rmv[0] = k.rm.x; rmv[1] = k.rm.y; rmv[2] = k.rm.z; rmv[3] = k.rm.w;
       rnv[0] = k.rn.x; rnv[1] = k.rn.y; rnv[2] = k.rn.z; rnv[3] = k.rn.w;
-      mrv[0] = k.mr.x; mrv[1] = k.mr.y; mrv[2] = k.mr.z; mrv[3] = k.mr.w;
+      if (LEAN) {           // -128 * s_res on the fly (exact): four registers less
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mrv[i] = -128.f * srv[i];
+      } else {
+        mrv[0] = k.mr.x; mrv[1] = k.mr.y; mrv[2] = k.mr.z; mrv[3] = k.mr.w;
+      }
     }
     float yy[2][4];
 #pragma unroll
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(512, 4) void k_gemm_i8(GemmArgs g) {
 //   DMA is pending (it cannot prove they do not alias), which would serialise the pipeline; __syncthreads() likewise drains vmcnt,
 //   hence the raw s_barrier.
 // ---------------------------------------------------------------------------------------------------
-#define DMA_STAGE_BYTES (2 * GBM * GBK)     // 16 KB: X tile + W tile (a packed int4 W tile fills half of its 8 KB)
+#define DMA_STAGE_BYTES (2 * GBM * GBK)     // 16 KB: X tile + W tile of the 128 x 128 form (a packed int4 W tile fills half of its 8 KB)
 // packed int4 weights: the W fragments are 8-byte reads of the [128][32 B] tile image, widened in registers (unpack_w4)
 template <int OFF>
 __device__ __forceinline__ void gemm_compute_tile_dma_w4(unsigned aX0, unsigned aX1, unsigned aW0, unsigned aW1, v16i (&acc)[2][2]) {
@@ -685,11 +694,25 @@ __device__ __forceinline__ void gemm_compute_tile_dma(unsigned aX0, unsigned aX1
   acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1b, x1b, acc[1][1], 0, 0, 0);
 }
 
-template <int EPI, int NST, bool W4>
-__global__ __launch_bounds__(256, NST == 2 ? 4 : 3) void k_gemm_dma(GemmArgs g) {
+// MT = waves along m: 2 -> 128 x 128 tile, 4 waves (3 workgroups per CU); 4 -> 256 x 128 tile, 8 waves, 2 workgroups per CU (round 3):
+// per k-tile 24 KB of operands feed 64 MFMAs instead of 16 KB feeding 32, i.e. 47 instead of 64 B/clk/CU of operand fetch at full
+// MFMA rate against the ~49 B/clk the CU's L1 delivers - the launcher picks it when the grid still fills the chip.
+#ifdef P2V_DIAG
+#define GD_STAMP(slot)                                                                                              \
+  do {                                                                                                              \
+    if (g.stamps && threadIdx.x == 0) g.stamps[(long long)blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter();  \
+  } while (0)
+#else
+#define GD_STAMP(slot) do { } while (0)
+#endif
+template <int EPI, int NST, bool W4, int MT>
+__global__ __launch_bounds__(128 * MT, MT == 4 ? 4 : (NST == 2 ? 4 : 3)) void k_gemm_dma(GemmArgs g) {
+  constexpr int TBM = 64 * MT;                                   // tile rows
+  constexpr int NTH = 128 * MT;                                  // threads
+  constexpr int STAGE = (TBM + GBN) * GBK;                       // X tile + W tile (a packed int4 W tile fills half of its 8 KB)
   constexpr int EPI_BYTES = (EPI == P2V_EPI_RESID) ? (int)sizeof(EpiLds) : 2 * GBN * (int)sizeof(float);   // colscale + bias only
-  __shared__ __attribute__((aligned(1024))) int8_t lds[NST * DMA_STAGE_BYTES + EPI_BYTES];
-  EpiLds* sE = reinterpret_cast<EpiLds*>(lds + NST * DMA_STAGE_BYTES);
+  __shared__ __attribute__((aligned(1024))) int8_t lds[NST * STAGE + EPI_BYTES];
+  EpiLds* sE = reinterpret_cast<EpiLds*>(lds + NST * STAGE);
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];   // GELU threshold table (cells * 8 bytes)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -698,9 +721,10 @@ __global__ __launch_bounds__(256, NST == 2 ? 4 : 3) void k_gemm_dma(GemmArgs g) 
   int bid = blockIdx.x, nt = gridDim.x, xcd = bid & 7, qd = nt >> 3, rm = nt & 7;
   int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
   const int tn = t % g.tiles_n, tm = t / g.tiles_n;
-  const int m0 = tm * GBM, n0 = tn * GBN;
+  const int m0 = tm * TBM, n0 = tn * GBN;
 
-  // ---- DMA source addresses: wave w moves rows [32w, 32w+32) of both tiles, two 16-row pieces each
+  // ---- DMA source addresses: wave w moves rows [32w, 32w+32) of the X tile (two 16-row pieces) and, of the 128-row W tile,
+  //      rows [32w, 32w+32) (MT = 2: two pieces) / [16w, 16w+16) (MT = 4: one piece)
   const int lr = lane >> 2, pc = lane & 3;
   const int ra = 32 * wave + lr, rb = ra + 16;
   int mra = m0 + ra, mrb = m0 + rb;
@@ -708,26 +732,35 @@ __global__ __launch_bounds__(256, NST == 2 ? 4 : 3) void k_gemm_dma(GemmArgs g) 
   mrb = mrb < g.M ? mrb : g.M - 1;
   const int8_t* gxa = g.A + (long long)mra * g.lda + ((pc ^ ((ra >> 2) & 3)) << 4);
   const int8_t* gxb = g.A + (long long)mrb * g.lda + ((pc ^ ((rb >> 2) & 3)) << 4);
-  const int8_t* gwa = g.W + (long long)(n0 + ra) * g.K + ((pc ^ ((ra >> 2) & 3)) << 4);
-  const int8_t* gwb = g.W + (long long)(n0 + rb) * g.K + ((pc ^ ((rb >> 2) & 3)) << 4);
-  // packed int4: the W tile of k-tile kt is the contiguous 4 KB LDS image (tn * nk + kt): one coalesced 1 KB piece per wave
-  const int8_t* gw4 = g.W + (long long)tn * (g.K / GBK) * 4096 + wave * 1024 + lane * 16;
+  const int wa = (MT == 4 ? 16 * wave : 32 * wave) + lr, wb = wa + 16;
+  const int8_t* gwa = g.W + (long long)(n0 + wa) * g.K + ((pc ^ ((wa >> 2) & 3)) << 4);
+  const int8_t* gwb = g.W + (long long)(n0 + wb) * g.K + ((pc ^ ((wb >> 2) & 3)) << 4);
+  // packed int4: the W tile of k-tile kt is the contiguous 4 KB LDS image (tn * nk + kt): one coalesced 1 KB piece per wave (MT = 2);
+  // with 8 waves each wave moves 512 bytes (its lower 32 lanes)
+  const int8_t* gw4 = g.W + (long long)tn * (g.K / GBK) * 4096 + (MT == 4 ? wave * 512 + (lane & 31) * 16 : wave * 1024 + lane * 16);
   auto dma = [&](int stage, int kt) {
-    int8_t* dst = lds + stage * DMA_STAGE_BYTES + wave * (32 * GBK);
+    int8_t* dst = lds + stage * STAGE + wave * (32 * GBK);
     const int ko = kt * GBK;
 #define P2V_DMA16_(SRC, DST) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
     P2V_DMA16_(gxa + ko, dst);
     P2V_DMA16_(gxb + ko, dst + 16 * GBK);
     if (W4) {
-      P2V_DMA16_(gw4 + (long long)kt * 4096, lds + stage * DMA_STAGE_BYTES + GBM * GBK + wave * 1024);
+      if (MT == 4) {
+        if (lane < 32) P2V_DMA16_(gw4 + (long long)kt * 4096, lds + stage * STAGE + TBM * GBK + wave * 512);
+      } else {
+        P2V_DMA16_(gw4 + (long long)kt * 4096, lds + stage * STAGE + TBM * GBK + wave * 1024);
+      }
+    } else if (MT == 4) {
+      P2V_DMA16_(gwa + ko, lds + stage * STAGE + TBM * GBK + wave * (16 * GBK));
     } else {
-      P2V_DMA16_(gwa + ko, dst + GBM * GBK);
-      P2V_DMA16_(gwb + ko, dst + GBM * GBK + 16 * GBK);
+      P2V_DMA16_(gwa + ko, dst + TBM * GBK);
+      P2V_DMA16_(gwb + ko, dst + TBM * GBK + 16 * GBK);
     }
 #undef P2V_DMA16_
   };
   const int nk = g.K / GBK;
+  GD_STAMP(0);
   dma(0, 0);
   if (nk > 1) dma(1, 1);
 
@@ -735,18 +768,22 @@ __global__ __launch_bounds__(256, NST == 2 ? 4 : 3) void k_gemm_dma(GemmArgs g) 
   //      k-tile needs anyway); residual codes requested early
   gemm_stage_epilogue<EPI>(sE, n0, tid, g);
   if (EPI == P2V_EPI_GELU_TAB)
-    for (int i = tid; i < g.ep.gelu.cells; i += 256)
+    for (int i = tid; i < g.ep.gelu.cells; i += NTH)
       reinterpret_cast<uint2*>(dyn_lds)[i] = reinterpret_cast<const uint2*>(g.ep.gelu.table)[i];
+  // MT = 2: all four 16-byte pieces a lane needs are requested before the k-loop; MT = 4 (128-VGPR budget, four waves per SIMD to
+  // cover the latency): two pieces at a time, right before the column group that consumes them
   uint4 resv[2][2];
-  if (EPI == P2V_EPI_RESID) {
+  auto load_resid = [&](int ni) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 64 + ni * 32 + 16 * h;
-        resv[ni][mi] = make_uint4(0, 0, 0, 0);
-        if (m < g.M && n < g.N) resv[ni][mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
-      }
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = m0 + wm * 64 + mi * 32 + l31, n = n0 + wn * 64 + ni * 32 + 16 * h;
+      resv[ni][mi] = make_uint4(0, 0, 0, 0);
+      if (m < g.M && n < g.N) resv[ni][mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
+    }
+  };
+  if (EPI == P2V_EPI_RESID && MT == 2) {
+    load_resid(0);
+    load_resid(1);
   }
 
   v16i acc[2][2];
@@ -759,27 +796,28 @@ __global__ __launch_bounds__(256, NST == 2 ? 4 : 3) void k_gemm_dma(GemmArgs g) 
 
   const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int8_t*)lds;
   const unsigned aX0 = lbase + lds_off64(wm * 64 + l31, h), aX1 = lbase + lds_off64(wm * 64 + 32 + l31, h);
-  const unsigned aW0 = lbase + GBM * GBK + (W4 ? lds_off_w4(wn * 64 + l31, h) : lds_off64(wn * 64 + l31, h));
-  const unsigned aW1 = lbase + GBM * GBK + (W4 ? lds_off_w4(wn * 64 + 32 + l31, h) : lds_off64(wn * 64 + 32 + l31, h));
-  constexpr int PCS = W4 ? 3 : 4;        // LDS-DMA requests of one wave per k-tile
+  const unsigned aW0 = lbase + TBM * GBK + (W4 ? lds_off_w4(wn * 64 + l31, h) : lds_off64(wn * 64 + l31, h));
+  const unsigned aW1 = lbase + TBM * GBK + (W4 ? lds_off_w4(wn * 64 + 32 + l31, h) : lds_off64(wn * 64 + 32 + l31, h));
+  constexpr int PCS = (W4 || MT == 4) ? 3 : 4;        // LDS-DMA requests of one wave per k-tile (exec-masked ones count as well)
+  GD_STAMP(1);
 
   // one k-tile: own pieces landed (younger requests stay in flight) -> barrier -> refill the freed stage -> MFMAs
 #define P2V_KTILE(S, KT)                                                                                             \
   do {                                                                                                               \
     if (NST == 3) {                                                                                                  \
-      /* in flight behind tile KT: tile KT+1 (4 requests of this wave) */                                            \
+      /* in flight behind tile KT: tile KT+1 (PCS requests of this wave) */                                          \
       if ((KT) + 1 < nk) { if (PCS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } \
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
       asm volatile("s_barrier" ::: "memory");    /* tile KT landed for everyone; everyone is done reading tile KT-1 */ \
       if ((KT) + 2 < nk) dma(((S) + 2) % 3, (KT) + 2);                                                               \
-      if (W4) gemm_compute_tile_dma_w4<(S) * DMA_STAGE_BYTES>(aX0, aX1, aW0, aW1, acc);                              \
-      else gemm_compute_tile_dma<(S) * DMA_STAGE_BYTES>(aX0, aX1, aW0, aW1, acc);                                    \
+      if (W4) gemm_compute_tile_dma_w4<(S) * STAGE>(aX0, aX1, aW0, aW1, acc);                                        \
+      else gemm_compute_tile_dma<(S) * STAGE>(aX0, aX1, aW0, aW1, acc);                                              \
     } else {                                                                                                         \
       if ((KT) + 1 < nk) { if (PCS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } \
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
       asm volatile("s_barrier" ::: "memory");                                                                        \
-      if (W4) gemm_compute_tile_dma_w4<(S) * DMA_STAGE_BYTES>(aX0, aX1, aW0, aW1, acc);                              \
-      else gemm_compute_tile_dma<(S) * DMA_STAGE_BYTES>(aX0, aX1, aW0, aW1, acc);                                    \
+      if (W4) gemm_compute_tile_dma_w4<(S) * STAGE>(aX0, aX1, aW0, aW1, acc);                                        \
+      else gemm_compute_tile_dma<(S) * STAGE>(aX0, aX1, aW0, aW1, acc);                                              \
       if ((KT) + 2 < nk) {                                                                                           \
         asm volatile("s_barrier" ::: "memory");                                                                      \
         dma((S), (KT) + 2);                                                                                          \
@@ -799,10 +837,19 @@ __global__ __launch_bounds__(256, NST == 2 ? 4 : 3) void k_gemm_dma(GemmArgs g) 
     }
   }
 #undef P2V_KTILE
+#ifdef P2V_DIAG
+  asm volatile("s_nop 0" :: "v"(acc[1][1][0]));
+#endif
+  GD_STAMP(2);
   __syncthreads();        // nothing is in flight any more; orders the constant stores before the epilogue reads for every wave
+  GD_STAMP(3);
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
-    gemm_epilogue_tile2<EPI>(acc[ni], m0 + wm * 64 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, sE, resv[ni], dyn_lds);
+  for (int ni = 0; ni < 2; ++ni) {
+    if (EPI == P2V_EPI_RESID && MT == 4) load_resid(ni);              // (held across the other group's epilogue they would spill)
+    gemm_epilogue_tile2<EPI, (MT == 4 && EPI == P2V_EPI_RESID)>(acc[ni], m0 + wm * 64 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, sE,
+                                                                 resv[ni], dyn_lds);
+  }
+  GD_STAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2115,31 +2162,57 @@ int p2v_launch_fill_cls(int8_t* x, int B, int T, int D, const int8_t* cls, hipSt
   return 0;
 }
 
+int g_gemm_tile = 0;      // P2V_GEMM_TILE: 0 = by grid size, 128 / 256 = force the tile height of the layer GEMMs
+static int device_cus() {
+  static int cus[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (!cus[dev]) {
+    hipDeviceProp_t pr;
+    cus[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+// dynamic LDS (the GELU table) of a tiled-GEMM instantiation beyond what it has been granted so far on this device
+template <typename K>
+static bool grant_dynamic_lds(K kernel, int slot, int bytes) {
+  static int granted[16][8] = {{0}};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+  if (dev >= 0 && bytes <= granted[dev][slot]) return true;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  if (dev >= 0) granted[dev][slot] = bytes;
+  return true;
+}
+
 int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   GemmArgs g = g0;
 #ifdef P2V_DIAG
   g.stamps = g_gemm_stamps;
 #endif
   g.tiles_n = (g.N + GBN - 1) / GBN;
-  const int tiles_m = (g.M + GBM - 1) / GBM;
   if (epi != P2V_EPI_HEAD && epi != P2V_EPI_EMBED) {
-    dim3 grid4(g.tiles_n * tiles_m), block4(256);
+    // 256-row tiles (8 waves, two workgroups per CU) when the grid still gives every CU its two workgroups; else 128-row tiles
+    const long long tiles256 = (long long)((g.M + 255) / 256) * g.tiles_n;
+    const bool big = g_gemm_stages == 3 && (g_gemm_tile == 256 || (g_gemm_tile == 0 && tiles256 >= 2LL * device_cus()));
+    const int tiles_m = big ? (g.M + 255) / 256 : (g.M + GBM - 1) / GBM;
+    dim3 grid4(g.tiles_n * tiles_m), block4(big ? 512 : 256);
     unsigned tab_bytes = (epi == P2V_EPI_GELU && g.ep.gelu.table) ? (unsigned)g.ep.gelu.cells * 8u : 0u;
     // static LDS of the GELU_TAB instantiations (ring + column constants) plus the table can pass the 64 KB a kernel gets by default
     // (1/scale = 256: 2111 cells = 16.5 KB): ask for the larger dynamic block once per process and device, or use the arithmetic epilogue
-    if (tab_bytes && g_gemm_stages * DMA_STAGE_BYTES + 2 * GBN * (int)sizeof(float) + (int)tab_bytes > 64 * 1024) {
-      static int granted[16][3] = {{0}};
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
-      const int which = g.w4 ? 2 : (g_gemm_stages == 2 ? 0 : 1);
-      if (dev < 0 || (int)tab_bytes > granted[dev][which]) {
-        const void* fn = g.w4 ? reinterpret_cast<const void*>(&k_gemm_dma<P2V_EPI_GELU_TAB, 3, true>)
-                              : (g_gemm_stages == 2 ? reinterpret_cast<const void*>(&k_gemm_dma<P2V_EPI_GELU_TAB, 2, false>)
-                                                    : reinterpret_cast<const void*>(&k_gemm_dma<P2V_EPI_GELU_TAB, 3, false>));
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes) != hipSuccess) {
-          (void)hipGetLastError();
-          tab_bytes = 0;                          // arithmetic P2V_EPI_GELU kernel: same codes, no table
-        } else if (dev >= 0) granted[dev][which] = (int)tab_bytes;
+    if (tab_bytes) {
+      const int stat = (big ? 3 * (256 + GBN) * GBK : g_gemm_stages * DMA_STAGE_BYTES) + 2 * GBN * (int)sizeof(float);
+      if (stat + (int)tab_bytes > 64 * 1024) {
+        bool ok;
+        if (big) ok = g.w4 ? grant_dynamic_lds(&k_gemm_dma<P2V_EPI_GELU_TAB, 3, true, 4>, 0, (int)tab_bytes)
+                           : grant_dynamic_lds(&k_gemm_dma<P2V_EPI_GELU_TAB, 3, false, 4>, 1, (int)tab_bytes);
+        else if (g.w4) ok = grant_dynamic_lds(&k_gemm_dma<P2V_EPI_GELU_TAB, 3, true, 2>, 2, (int)tab_bytes);
+        else if (g_gemm_stages == 2) ok = grant_dynamic_lds(&k_gemm_dma<P2V_EPI_GELU_TAB, 2, false, 2>, 3, (int)tab_bytes);
+        else ok = grant_dynamic_lds(&k_gemm_dma<P2V_EPI_GELU_TAB, 3, false, 2>, 4, (int)tab_bytes);
+        if (!ok) tab_bytes = 0;                   // arithmetic P2V_EPI_GELU kernel: same codes, no table
       }
     }
 #define P2V_LAUNCH_TILED(KERNEL)                                                                                          \
@@ -2152,10 +2225,15 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
       case P2V_EPI_RESID: hipLaunchKernelGGL(KERNEL(P2V_EPI_RESID), grid4, block4, 0, st, g); break;                      \
       default: return -1;                                                                                                 \
     }
-#define P2V_K_DMA2(E) (k_gemm_dma<E, 2, false>)
-#define P2V_K_DMA3(E) (k_gemm_dma<E, 3, false>)
-#define P2V_K_DMA3P(E) (k_gemm_dma<E, 3, true>)
-    if (g.w4) { P2V_LAUNCH_TILED(P2V_K_DMA3P) }          // packed int4 weights: the LDS-DMA kernel only
+#define P2V_K_DMA2(E) (k_gemm_dma<E, 2, false, 2>)
+#define P2V_K_DMA3(E) (k_gemm_dma<E, 3, false, 2>)
+#define P2V_K_DMA3P(E) (k_gemm_dma<E, 3, true, 2>)
+#define P2V_K_DMA3L(E) (k_gemm_dma<E, 3, false, 4>)
+#define P2V_K_DMA3PL(E) (k_gemm_dma<E, 3, true, 4>)
+    if (big) {
+      if (g.w4) { P2V_LAUNCH_TILED(P2V_K_DMA3PL) }
+      else { P2V_LAUNCH_TILED(P2V_K_DMA3L) }
+    } else if (g.w4) { P2V_LAUNCH_TILED(P2V_K_DMA3P) }          // packed int4 weights: the LDS-DMA kernel only
     else if (g_gemm_stages == 2) { P2V_LAUNCH_TILED(P2V_K_DMA2) }
     else { P2V_LAUNCH_TILED(P2V_K_DMA3) }
 #undef P2V_LAUNCH_TILED
@@ -2163,6 +2241,7 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
     return 0;
   }
   // EMBED / HEAD: one launch each per forward; 8-wave shape (64x32 wave tiles, <= 128 VGPRs)
+  const int tiles_m = (g.M + GBM - 1) / GBM;
   dim3 grid(g.tiles_n * tiles_m), block(512);
   if (epi == P2V_EPI_EMBED) {
     if (g.w4) hipLaunchKernelGGL((k_gemm_i8<P2V_EPI_EMBED, true>), grid, block, 0, st, g);
@@ -2253,12 +2332,17 @@ int p2v_launch_layernorm(const LnArgs& a_, hipStream_t st) {
   a.force_generic = g_ln_generic;
   a.rows_per_half = g_ln_rows;
   const int LN_ROWS = g_ln_rows;
-  const bool wide = a.C > 1024;                 // one row per wave (64 lanes x 4 channels x up to 8 groups = 2048 channels)
+  // one row per WAVE above 384 channels (64 lanes x 4 channels x up to 8 groups = 2048 channels): the per-lane constants of a half-wave
+  // row cost ~45 VGPRs per 128 channels (C = 768: 256 VGPRs, one wave per SIMD; a wave per row: 161, three)
+  const bool wide = a.C > 384;
   const int nch = wide ? (a.C + 255) / 256 : (a.C + 127) / 128;
   const int rows_per_block = (wide ? 4 : 8) * LN_ROWS;
   dim3 grid((unsigned)((a.rows + rows_per_block - 1) / rows_per_block)), block(256);
   if (wide) {
     switch (nch) {
+      case 2: hipLaunchKernelGGL((k_int_layernorm<2, 64>), grid, block, 0, st, a); break;
+      case 3: hipLaunchKernelGGL((k_int_layernorm<3, 64>), grid, block, 0, st, a); break;
+      case 4: hipLaunchKernelGGL((k_int_layernorm<4, 64>), grid, block, 0, st, a); break;
       case 5: hipLaunchKernelGGL((k_int_layernorm<5, 64>), grid, block, 0, st, a); break;
       case 6: hipLaunchKernelGGL((k_int_layernorm<6, 64>), grid, block, 0, st, a); break;
       case 7: hipLaunchKernelGGL((k_int_layernorm<7, 64>), grid, block, 0, st, a); break;
@@ -2270,11 +2354,6 @@ int p2v_launch_layernorm(const LnArgs& a_, hipStream_t st) {
       case 1: hipLaunchKernelGGL((k_int_layernorm<1, 32>), grid, block, 0, st, a); break;
       case 2: hipLaunchKernelGGL((k_int_layernorm<2, 32>), grid, block, 0, st, a); break;
       case 3: hipLaunchKernelGGL((k_int_layernorm<3, 32>), grid, block, 0, st, a); break;
-      case 4: hipLaunchKernelGGL((k_int_layernorm<4, 32>), grid, block, 0, st, a); break;
-      case 5: hipLaunchKernelGGL((k_int_layernorm<5, 32>), grid, block, 0, st, a); break;
-      case 6: hipLaunchKernelGGL((k_int_layernorm<6, 32>), grid, block, 0, st, a); break;
-      case 7: hipLaunchKernelGGL((k_int_layernorm<7, 32>), grid, block, 0, st, a); break;
-      case 8: hipLaunchKernelGGL((k_int_layernorm<8, 32>), grid, block, 0, st, a); break;
       default: return -1;
     }
   }

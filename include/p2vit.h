@@ -358,10 +358,11 @@ const char* p2v_last_error(void);
 int p2v_abi_version(void);
 
 /* Scheduling / A-B switches of the process (also read once from the environment: P2V_LN_GEMM, P2V_LN_GEMM_V, P2V_LN_GENERIC,
- * P2V_LN_ROWS, P2V_ATTN_WAVES, P2V_GEMM_STAGES).  None of them changes a result - every variant is bit-identical and is driven
+ * P2V_LN_ROWS, P2V_ATTN_WAVES, P2V_GEMM_STAGES, P2V_GEMM_TILE).  None of them changes a result - every variant is bit-identical and is driven
  * through this call by the parity tests:
  *   "ln_gemm" 0/1 (fuse LayerNorm into qkv / fc1), "ln_gemm_version" 1/2 (4-wave / 8-wave pipelined fused kernel),
- *   "ln_generic" 0/1 (generic LayerNorm chain), "ln_rows" 1..64, "attn_waves" 4..8, "gemm_stages" 2/3. */
+ *   "ln_generic" 0/1 (generic LayerNorm chain), "ln_rows" 1..64, "attn_waves" 4..8, "gemm_stages" 2/3,
+ *   "gemm_tile" 0/128/256 (tile height of the layer GEMMs; 0 = 256 rows when the grid still fills the chip). */
 int p2v_set_tuning(const char* name, int value);
 
 #ifdef __cplusplus

@@ -1038,3 +1038,54 @@ def test_bench_rccl_branch_on_one_gpu(dva):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 1 and d['config']['backend'] == 'nccl' and d['config']['collective'] == 'all_gather(logits)'
     assert d['config']['gathered_logits_equal_per_rank_forwards'] is True and d['value'] > 0
+
+
+@pytest.mark.parametrize('M,K,N', [(777, 128, 256), (1000, 448, 384), (261, 768, 128)])
+def test_gemm_256_row_tiles_equal_128_row_tiles(dva, oracle, M, K, N):
+    """the 256 x 128 tile form of the layer GEMMs (8 waves, picked by the launcher for large grids; "gemm_tile" forces it here) gives the
+    bytes of the 128 x 128 form for every epilogue and both weight formats, ragged M included; the RESID case also against the oracle."""
+    E, S = dva.engine, dva.synth
+    L = E.lib()
+    tag = 't%d' % M
+    x = _rand_codes(S, 21, tag + 'x', (M, K)); w = _rand_codes(S, 21, tag + 'w', (N, K), 30.0)
+    w4 = torch.clamp(torch.round(w / 16.0), -8, 7)
+    bias = S.normal(21, tag + 'b', (N,), 0.4)
+    res = _rand_codes(S, 21, tag + 'r', (M, N), 50.0)
+    ptf = lambda nm, base: base * 2.0 ** torch.floor(S.uniform(21, tag + nm, (N,), 0, 3.99))
+    s_mid, s_res, s_next = ptf('m', 0.0131), ptf('r2', 0.0173), ptf('n', 0.0209)
+    s_x, s_w = 2.0 ** -5, 2.0 ** -8
+    xd = x.to(torch.int8).cuda()
+    cs = torch.full((N,), s_x * s_w).cuda(); bd = bias.cuda()
+    wd = w.to(torch.int8).cuda()
+    wp = E.pack_int4_tiles(w4.to(torch.int8)).cuda()
+    cs4 = torch.full((N,), s_x * s_w * 16).cuda()
+    dev = [t.cuda() for t in (s_mid, s_res, s_next)]
+    resd = res.to(torch.int8).cuda()
+    tab = E.gelu_table(2.0 ** 5, 'cuda')
+    outs = {}
+    try:
+        for tile in (128, 256):
+            E.check(L.p2v_set_tuning(b'gemm_tile', tile))
+            for wname, lin in (('w8', E.Linear(E.ptr(wd), E.ptr(cs), E.ptr(bd), None, 0)), ('w4', E.Linear(E.ptr(wp), E.ptr(cs4), E.ptr(bd), None, 1))):
+                for ename, ek in (('requant', E.EPI_REQUANT), ('gelu', E.EPI_GELU), ('gelu_tab', E.EPI_GELU), ('resid', E.EPI_RESID)):
+                    epi = E.Epilogue()
+                    epi.inv_s_out = 2.0 ** 3 if ename == 'requant' else 2.0 ** 5
+                    if ename == 'gelu_tab':
+                        epi.gelu = tab
+                    if ename == 'resid':
+                        epi.s_mid, epi.s_res, epi.s_next, epi.residual = E.ptr(dev[0]), E.ptr(dev[1]), E.ptr(dev[2]), E.ptr(resd)
+                    out = torch.full((M, N), 91, dtype=torch.int8, device='cuda')
+                    E.check(L.p2v_gemm_i8(ek, E.ptr(xd), K, M, K, N, C.byref(lin), C.byref(epi), E.ptr(out), N, None, E.stream_ptr()))
+                    torch.cuda.synchronize()
+                    outs[(tile, wname, ename)] = out.cpu()
+    finally:
+        E.check(L.p2v_set_tuning(b'gemm_tile', 0))
+    for (tile, wname, ename), o in outs.items():
+        if tile == 256:
+            ref = outs[(128, wname, ename)]
+            assert torch.equal(o, ref), (wname, ename, int((o != ref).sum()))
+    y = oracle.qgemm(x, torch.tensor(s_x), w, torch.full((N,), s_w), bias)
+    q3 = torch.clamp(torch.round(y / s_mid), -128, 127)
+    ref = torch.clamp(torch.round((res * s_res + q3 * s_mid) / s_next), -128, 127)
+    assert torch.equal(outs[(256, 'w8', 'resid')].float(), ref)
+    assert torch.equal(outs[(128, 'w8', 'gelu')], outs[(128, 'w8', 'gelu_tab')])
