@@ -231,6 +231,8 @@ def main():
     B = args.batch
     # every image of the batch is distinct (counter-based generator, seed 1000 + rank)
     x = base.repeat((B + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
+    if os.environ.get('P2V_BENCH_CONST_INPUT'):      # experiment (profiles/r03_slicing.txt): every image identical and constant -> low operand toggling
+        x.fill_(0.25)
     bits = [args.bits] * (4 * arch['depth'] + 2)
     logits = torch.empty(B, arch['num_classes'], device=dev)
     # == model(x, bits)[0]; the per-GPU batch runs as contiguous slices on their own HIP streams (images are independent; the kernels

@@ -139,10 +139,10 @@ int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
   const int hd = d.embed_dim / d.num_heads;
   if (hd != 32 && hd != 64) return fail(P2V_E_UNSUPPORTED, "head_dim %d (32 and 64 are instantiated)", hd);
   if (d.embed_dim % 64 || d.mlp_hidden % 64) return fail(P2V_E_UNSUPPORTED, "embed_dim and mlp_hidden must be multiples of 64");
-  {   // the attention kernel is instantiated for ceil(tokens / 32) in {1, 2, 7}: refuse other geometries here, before any upload
-    const int tokens = (d.img_size / d.patch_size) * (d.img_size / d.patch_size) + 1, nkb = (tokens + 31) / 32;
-    if (nkb != 1 && nkb != 2 && nkb != 7)
-      return fail(P2V_E_UNSUPPORTED, "%d tokens per image: the attention kernel covers <= 64 and 193..224 tokens (224^2 / 16)", tokens);
+  {   // the attention kernel keeps a query block's scores in registers and K / V^T of an image in LDS: up to 608 tokens (19 key pairs)
+    const int tokens = (d.img_size / d.patch_size) * (d.img_size / d.patch_size) + 1;
+    if (tokens > P2V_MAX_TOKENS)
+      return fail(P2V_E_UNSUPPORTED, "%d tokens per image: the attention kernel covers up to %d (e.g. 384^2 / 16 = 577)", tokens, P2V_MAX_TOKENS);
   }
   if (d.embed_dim > 2048) return fail(P2V_E_UNSUPPORTED, "embed_dim %d: the LayerNorm kernel covers up to 2048 channels", d.embed_dim);
   p2v_plan* p = new p2v_plan();

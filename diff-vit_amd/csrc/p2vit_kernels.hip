@@ -1622,8 +1622,11 @@ extern unsigned long long* g_gemm_stamps;
 #else
 #define AT_STAMP(slot) do { } while (0)
 #endif
-template <int HD, int NKP, bool TAP, bool ISH>   // NKP = 32-key pairs covering the tokens (7 for 197); TAP: also write probs_k
-__global__ __launch_bounds__(512, 4) void k_lis_attention(AttnArgs a) {
+// NKP = 32-key pairs covering the tokens (7 for 197; 19 for the 577 tokens of 384^2 / 16); TAP: also write probs_k.  The score slots of a
+// query block live in registers (8 per 32-key pair): up to NKP = 7 the kernel fits 128 VGPRs (four waves per SIMD), up to 10 it takes 168,
+// beyond that 256 (one 8-wave workgroup per CU; K / V^T of 608 keys x head_dim 64 need 121 KB of LDS).
+template <int HD, int NKP, bool TAP, bool ISH>
+__global__ __launch_bounds__(512, NKP <= 7 ? 4 : (NKP <= 10 ? 3 : 2)) void k_lis_attention(AttnArgs a) {
   constexpr int KROWS = NKP * 32;
   constexpr int NKB = NKP * 2;                  // 16-key blocks
   constexpr int VSTRIDE = KROWS + 4;            // bf16 elements; dword stride = 2*odd -> conflict-free b64 reads
@@ -2375,13 +2378,29 @@ static int launch_attn_t(const AttnArgs& a_, hipStream_t st) {
   a.stamps = g_gemm_stamps;
 #endif
   const dim3 grid(a.B * a.H), block(64 * g_attn_waves);
+#define P2V_ATTN_LAUNCH(TAP_, ISH_)                                                                                          \
+  do {                                                                                                                       \
+    if (smem > 64 * 1024) {          /* K and V^T of more than ~300 keys: beyond the default dynamic LDS limit */            \
+      static bool granted[16] = {false};                                                                                     \
+      int dev = 0;                                                                                                           \
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;                                                \
+      if (dev < 0 || !granted[dev]) {                                                                                        \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lis_attention<HD, NKB, TAP_, ISH_>),             \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                           \
+        if (e != hipSuccess) return (int)e;                                                                                  \
+        if (dev >= 0) granted[dev] = true;                                                                                   \
+      }                                                                                                                      \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((k_lis_attention<HD, NKB, TAP_, ISH_>), grid, block, smem, st, a);                                    \
+  } while (0)
   if (a.probs_k) {
-    if (a.pshift) hipLaunchKernelGGL((k_lis_attention<HD, NKB, true, true>), grid, block, smem, st, a);
-    else hipLaunchKernelGGL((k_lis_attention<HD, NKB, true, false>), grid, block, smem, st, a);
+    if (a.pshift) P2V_ATTN_LAUNCH(true, true);
+    else P2V_ATTN_LAUNCH(true, false);
   } else {
-    if (a.pshift) hipLaunchKernelGGL((k_lis_attention<HD, NKB, false, true>), grid, block, smem, st, a);
-    else hipLaunchKernelGGL((k_lis_attention<HD, NKB, false, false>), grid, block, smem, st, a);
+    if (a.pshift) P2V_ATTN_LAUNCH(false, true);
+    else P2V_ATTN_LAUNCH(false, false);
   }
+#undef P2V_ATTN_LAUNCH
   CHECK_LAUNCH();
   return 0;
 }
@@ -2452,21 +2471,24 @@ int p2v_launch_attention(const AttnArgs& a, int head_dim, hipStream_t st) {
     const float m2 = a.at.s_qkv_sq * a.at.inv_s_attn;
     if (!(m2 > 0.f) || frexpf(m2, &ex) != 0.5f) return -2;
   }
-  if (head_dim == 64) {
-    switch (nkb) {
-      case 1: return launch_attn_t<64, 1>(a, st);
-      case 2: return launch_attn_t<64, 2>(a, st);
-      case 7: return launch_attn_t<64, 7>(a, st);
-      default: return -1;
-    }
-  } else if (head_dim == 32) {
-    switch (nkb) {
-      case 1: return launch_attn_t<32, 1>(a, st);
-      case 2: return launch_attn_t<32, 2>(a, st);
-      case 7: return launch_attn_t<32, 7>(a, st);
-      default: return -1;
-    }
+  // every ceil(tokens / 32) up to 19 (608 tokens) is instantiated: the padding of a launch is always less than one 32-key pair
+#define P2V_ATTN_CASES(HD_)                                                                                                  \
+  switch (nkb) {                                                                                                             \
+    case 1: return launch_attn_t<HD_, 1>(a, st);   case 2: return launch_attn_t<HD_, 2>(a, st);                              \
+    case 3: return launch_attn_t<HD_, 3>(a, st);   case 4: return launch_attn_t<HD_, 4>(a, st);                              \
+    case 5: return launch_attn_t<HD_, 5>(a, st);   case 6: return launch_attn_t<HD_, 6>(a, st);                              \
+    case 7: return launch_attn_t<HD_, 7>(a, st);   case 8: return launch_attn_t<HD_, 8>(a, st);                              \
+    case 9: return launch_attn_t<HD_, 9>(a, st);   case 10: return launch_attn_t<HD_, 10>(a, st);                            \
+    case 11: return launch_attn_t<HD_, 11>(a, st); case 12: return launch_attn_t<HD_, 12>(a, st);                            \
+    case 13: return launch_attn_t<HD_, 13>(a, st); case 14: return launch_attn_t<HD_, 14>(a, st);                            \
+    case 15: return launch_attn_t<HD_, 15>(a, st); case 16: return launch_attn_t<HD_, 16>(a, st);                            \
+    case 17: return launch_attn_t<HD_, 17>(a, st); case 18: return launch_attn_t<HD_, 18>(a, st);                            \
+    case 19: return launch_attn_t<HD_, 19>(a, st);                                                                           \
+    default: return -1;                                                                                                      \
   }
+  if (head_dim == 64) { P2V_ATTN_CASES(64) }
+  if (head_dim == 32) { P2V_ATTN_CASES(32) }
+#undef P2V_ATTN_CASES
   return -1;
 }
 

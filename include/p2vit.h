@@ -20,8 +20,8 @@
  *     per-channel PTF scales (ptf.py:51,133) are arbitrary fp32 and are divided by, as the reference does.
  *
  * Limits of what is instantiated (everything else returns P2V_E_UNSUPPORTED, at plan creation where the geometry is known):
- *   - ViT attention: head_dim 32 or 64; tokens per image <= 64 or 193..224 (i.e. 224^2 / 16 and the test geometries; 384^2 is not
- *     built); Swin window attention: head_dim 32, windows up to 8 x 8;
+ *   - ViT attention: head_dim 32 or 64; up to P2V_MAX_TOKENS = 608 tokens per image (224^2 / 16 = 197, 384^2 / 16 = 577, ...);
+ *     Swin window attention: head_dim 32, windows up to 8 x 8;
  *   - LayerNorm: up to 2048 channels, PTF input masks (in_scale / min in_scale) in {1, 2, 4, 8};
  *   - LayerNorm output scale: p2v_ln.inv_out is MULTIPLIED by where the reference divides by the scale - identical for the power-of-two
  *     scales of this path; for any other scale pass p2v_ln.out_scale too and the kernel divides (exact, ABI 3);
@@ -39,6 +39,7 @@ extern "C" {
 #endif
 
 #define P2V_ABI_VERSION 3
+#define P2V_MAX_TOKENS 608   /* tokens per image of the ViT attention kernel (19 pairs of 32 keys) */
 
 enum {
   P2V_OK = 0,

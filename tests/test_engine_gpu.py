@@ -412,7 +412,10 @@ def test_ln_gemm_fused_vs_separate_and_oracle(dva, oracle, C_, N, M, kind, table
 
 
 @pytest.mark.parametrize('B,N,H,hd,e_at', [(2, 17, 2, 32, 4), (3, 49, 4, 32, 5), (2, 197, 3, 64, 4), (1, 197, 6, 64, 6), (2, 50, 2, 64, 3),
-                                          (1, 193, 2, 64, 5), (1, 224, 2, 64, 4), (1, 209, 1, 32, 4), (1, 64, 2, 64, 4), (1, 1, 1, 32, 4)])
+                                          (1, 193, 2, 64, 5), (1, 224, 2, 64, 4), (1, 209, 1, 32, 4), (1, 64, 2, 64, 4), (1, 1, 1, 32, 4),
+                                          # any token count up to 608 (round 3): 65 / 128 / 145 / 257 / 320 / 577 (384^2 / 16) / 608 tokens
+                                          (2, 65, 3, 32, 4), (2, 128, 2, 64, 4), (1, 145, 2, 64, 5), (1, 257, 2, 64, 4), (1, 320, 1, 32, 4),
+                                          (1, 577, 2, 64, 5), (1, 577, 1, 32, 4), (1, 608, 1, 64, 4)])
 def test_lis_attention(dva, oracle, B, N, H, hd, e_at):
     E, S = dva.engine, dva.synth
     D = H * hd
@@ -706,6 +709,34 @@ def test_other_configs_engine_vs_oracle(dva, oracle, name, bits):
         ref = orc.quant_forward(x, bc)
         assert torch.equal(out.cpu(), ref), (name, bc[:6], int((out.cpu() != ref).sum()))
         assert flops == orc.flops()
+
+
+@pytest.mark.parametrize('img,patch,dim,depth,heads', [(384, 16, 128, 2, 2), (96, 8, 64, 2, 2), (160, 16, 128, 2, 4)])
+def test_other_token_counts_engine_vs_oracle(dva, oracle, img, patch, dim, depth, heads):
+    """VisionTransformer takes any img_size (vit_fquant.py:494,535-540): 384^2 / 16 = 577 tokens (the 384-pixel ViT / DeiT variants), 145 and
+    101 tokens: the whole quantized forward through the drop-in surface equals the oracle on every logit; 609+ tokens are refused when the
+    plan is created."""
+    arch = dict(img_size=img, patch_size=patch, embed_dim=dim, depth=depth, num_heads=heads, num_classes=40, mlp_ratio=4.0)
+    sd = dva.synth.vit_state_dict(arch, 33)
+    m = dva.VisionTransformer(img_size=img, patch_size=patch, embed_dim=dim, depth=depth, num_heads=heads, num_classes=40, mlp_ratio=4.0, qkv_bias=True,
+                              norm_layer=partial(dva.QIntLayerNorm, eps=1e-6), input_quant=True, cfg=dva.Config())
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda().eval()
+    dva.harness.calibrate_model(m, dva.synth.images(33, 2, img).cuda())
+    x = dva.synth.images(33, 3, img, offset=700)
+    L = 4 * depth + 2
+    orc = oracle.OracleViT(arch, sd)
+    orc.calib = m.export_calib()
+    for bc in ([8] * L, [4] * L):
+        out = m(x.cuda(), bc, False)[0]
+        ref = orc.quant_forward(x, bc)
+        assert torch.equal(out.cpu(), ref), (img, bc[0], int((out.cpu() != ref).sum()))
+    if img == 384:
+        big = dva.VisionTransformer(img_size=400, patch_size=16, embed_dim=dim, depth=1, num_heads=heads, num_classes=10, mlp_ratio=4.0, qkv_bias=True,
+                                    norm_layer=partial(dva.QIntLayerNorm, eps=1e-6), input_quant=True, cfg=dva.Config()).cuda().eval()
+        dva.harness.calibrate_model(big, dva.synth.images(33, 1, 400).cuda())
+        with pytest.raises(NotImplementedError):          # 626 tokens: P2V_MAX_TOKENS = 608
+            big(dva.synth.images(33, 1, 400).cuda(), [8] * 6)
 
 
 def test_custom_ops_match_c_abi(dva, oracle, micro):
