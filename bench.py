@@ -288,6 +288,11 @@ def main():
         ach = byts / (avg_ms * 1e-3) / 1e9
         roof = dict(kernel=dom, bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                     frac=round(ach / PEAK_HBM_GBS, 4))
+    # what the matrix pipe sustains on real data under the board's power limit (tools/ubench/mfma_power.hip, profiles/r03_mfma_power.txt):
+    # the guide's peak is reached only with constant operands; listed beside it, never used for `frac`
+    if roof['bound'] == 'mfma':
+        roof['peak_sustained_measured'] = {'random_operands_in_registers': 3400.0, 'operands_from_lds': 2630.0, 'unit': 'TFLOP/s',
+                                           'source': 'profiles/r03_mfma_power.txt (power-limited clock 1.66 / 1.41 GHz)'}
     roof['avg_launch_us'] = round(avg_ms * 1e3, 2)
     roof['launches_per_step'] = n_sl * (len(prof[dom]) // 5)
     roof['images_per_launch'] = Bl
@@ -304,6 +309,21 @@ def main():
         except Exception:
             pass
     breakdown = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
+    # the same launches WHILE the other slices' kernels run (the regime the headline is measured in): HIP events on every slice's
+    # stream, three steps back to back, the middle one reported (FrozenPlan.profile_streams; the events cost ~3 us per launch)
+    ovl, ovl_wall = {}, None
+    if n_sl > 1:
+        acc_o = {}
+        walls = []
+        for _ in range(3):
+            per, wall = plan.profile_streams(x, bits, args.streams, slices, rounds=3)
+            walls.append(wall)
+            for pslice in per:
+                for kind, ms in pslice:
+                    acc_o.setdefault(kind, []).append(ms)
+        ovl = {k: round(sum(v) / len(v) * 1e3, 2) for k, v in acc_o.items()}
+        ovl_wall = round(sorted(walls)[1], 3)
+    iso_us = {k: round(sum(v) / len(v) * 1e3, 2) for k, v in prof.items()}
     model_ops = sum(algorithmic_work(k, arch, Bl, args.bits)[0] * n_sl * (len(v) // 5) for k, v in prof.items())
 
     cpu = None
@@ -369,6 +389,9 @@ def main():
             'top1_agreement_fp32': round(top1_fp32, 4),
             'model_mfma_frac': round(model_ops / (el / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
             'kernel_ms_per_step': breakdown,
+            'kernel_us_per_launch': {k: {'isolated': iso_us[k], 'under_overlap': ovl.get(k)} for k in sorted(iso_us, key=lambda k: -tot[k])},
+            'overlap': {'longest_stream_ms_with_events': ovl_wall, 'note': 'under_overlap = launch duration while the other slices run (HIP events on each '
+                        'stream, FrozenPlan.profile_streams); isolated = one slice alone'} if ovl else None,
             'cpu_baseline': cpu,
             'calibration': {'seconds': round(t_cal, 2), 'device': 'host cpu (float pass + observer searches; harness.calibrate_model where=host)', 'tensors': len(ref_calib), 'tensors_bit_equal_reference': n_equal,
                             'scale_elements': n_elems, 'elements_off_by_a_power_of_two': exp_flips},

@@ -92,3 +92,37 @@ def load_checkpoint(model, path, strict=False):
     if bad:
         raise ValueError('checkpoint/model shape mismatch for %s' % bad[:4])
     return model.load_state_dict(sd, strict=strict)
+
+
+# file names of the checkpoints the reference's factories fetch (vit_fquant.py:822-828,849-855,876-882,904-907,929-932;
+# swin_quant.py:838-844,866-872,894-900): torch.hub stores a download under <hub dir>/checkpoints/<basename of the URL>
+PRETRAINED_FILES = {
+    'deit_tiny_patch16_224': 'deit_tiny_patch16_224-a1311bcf.pth',
+    'deit_small_patch16_224': 'deit_small_patch16_224-cd65a155.pth',
+    'deit_base_patch16_224': 'deit_base_patch16_224-b5f2ef4d.pth',
+    'vit_base_patch16_224': 'B_16-i21k-300ep-lr_0.001-aug_medium1-wd_0.1-do_0.0-sd_0.0--imagenet2012-steps_20k-lr_0.01-res_224.npz',
+    'vit_large_patch16_224': 'L_16-i21k-300ep-lr_0.001-aug_medium1-wd_0.1-do_0.1-sd_0.1--imagenet2012-steps_20k-lr_0.01-res_224.npz',
+    'swin_tiny_patch4_window7_224': 'swin_tiny_patch4_window7_224.pth',
+    'swin_small_patch4_window7_224': 'swin_small_patch4_window7_224.pth',
+    'swin_base_patch4_window7_224': 'swin_base_patch4_window7_224.pth',
+}
+
+
+def pretrained_path(factory_name):
+    """where ``pretrained=True`` of the reference's factory of that name keeps its download: ``torch.hub.get_dir()/checkpoints/<file>``
+    (``TORCH_HOME`` moves the hub directory)."""
+    import os
+    return os.path.join(torch.hub.get_dir(), 'checkpoints', PRETRAINED_FILES[factory_name])
+
+
+def load_pretrained(model, factory_name):
+    """``pretrained=True``: the reference downloads the checkpoint into the torch-hub cache and loads it with ``strict=False``
+    (vit_fquant.py:822-828).  Here the SAME cache file is loaded when it is already there (nothing is fetched: no network), with
+    loaders that execute nothing from the file; a missing file is a ``FileNotFoundError`` naming the path to put it at."""
+    import os
+    path = pretrained_path(factory_name)
+    if not os.path.exists(path):
+        raise FileNotFoundError('pretrained=True: %s is not in the torch-hub cache (the reference would download it; there is no network here). '
+                                'Place the file at %s or load a local checkpoint with checkpoint.load_checkpoint(model, path).'
+                                % (PRETRAINED_FILES[factory_name], path))
+    return load_checkpoint(model, path)

@@ -45,6 +45,8 @@ def build_parser():
     p.add_argument('--real-data', default=False, action='store_true',
                    help='evaluate on the ImageFolder tree under --data (val/, and train/ for --mode 0 calibration) through the PIL port of '
                         'build_transform (data.py; its equality with torchvision is unpinned)')
+    p.add_argument('--pretrained', default=False, action='store_true', help='like the reference (test_quant.py:95): the checkpoint of the '
+                   'torch-hub cache, <TORCH_HOME>/hub/checkpoints/<file> (checkpoint.PRETRAINED_FILES); never downloaded here')
     p.add_argument('--checkpoint', default='', help='local .pth / .npz checkpoint (checkpoint.load_checkpoint); default: seeded synthetic weights')
     p.add_argument('--n-val', default=500, type=int, help='number of synthetic validation images')
     p.add_argument('--bits', default=8, type=int, choices=[4, 8], help='uniform bit_config for the validation run')
@@ -205,9 +207,11 @@ def main(argv=None):
     seed(args.seed)
     device = torch.device(args.device)
     cfg = Config(args.ptf, args.lis, args.quant_method)
-    model = str2model(args.model)(pretrained=False, cfg=cfg)
+    model = str2model(args.model)(pretrained=args.pretrained, cfg=cfg)
     arch = model.arch
-    if _is_swin(model):
+    if args.pretrained:
+        pass
+    elif _is_swin(model):
         model.load_state_dict(synth.swin_state_dict(model.state_dict(), args.seed))
     else:
         model.load_state_dict(synth.vit_state_dict(arch, args.seed), strict=False)

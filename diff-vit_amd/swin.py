@@ -335,17 +335,23 @@ class SwinTransformer(nn.Module):
         return self.act_out(self.head(self.forward_features(x)))
 
 
-def _factory(embed_dim, depths, num_heads, img_size=224):
+def _factory(name, embed_dim, depths, num_heads, img_size=224):
     def make(pretrained=False, quant=False, calibrate=False, cfg=None, **kwargs):
-        if pretrained:
-            raise RuntimeError('no network in this environment: load a local checkpoint with load_state_dict(...)')
+        if cfg is None:
+            from .config import Config
+            cfg = Config()
         kw = dict(patch_size=4, window_size=7, embed_dim=embed_dim, depths=depths, num_heads=num_heads, img_size=img_size)
         kw.update(kwargs)
-        return SwinTransformer(norm_layer=QIntLayerNorm, quant=quant, calibrate=calibrate, input_quant=True, cfg=cfg, **kw)
+        model = SwinTransformer(norm_layer=QIntLayerNorm, quant=quant, calibrate=calibrate, input_quant=True, cfg=cfg, **kw)
+        if pretrained:       # swin_quant.py:838-844: the checkpoint of the torch-hub cache (never fetched here: checkpoint.load_pretrained)
+            from .checkpoint import load_pretrained
+            load_pretrained(model, name)
+        return model
+    make.__name__ = name
     return make
 
 
-swin_tiny_patch4_window7_224 = _factory(96, (2, 2, 6, 2), (3, 6, 12, 24))
-swin_small_patch4_window7_224 = _factory(96, (2, 2, 18, 2), (3, 6, 12, 24))
-swin_base_patch4_window7_224 = _factory(128, (2, 2, 18, 2), (4, 8, 16, 32))
-swin_micro_patch4_window7_56 = _factory(64, (2, 2), (2, 4), img_size=56)     # 14x14 -> 7x7 tokens: both shift/no-shift and one merge
+swin_tiny_patch4_window7_224 = _factory('swin_tiny_patch4_window7_224', 96, (2, 2, 6, 2), (3, 6, 12, 24))
+swin_small_patch4_window7_224 = _factory('swin_small_patch4_window7_224', 96, (2, 2, 18, 2), (3, 6, 12, 24))
+swin_base_patch4_window7_224 = _factory('swin_base_patch4_window7_224', 128, (2, 2, 18, 2), (4, 8, 16, 32))
+swin_micro_patch4_window7_56 = _factory('swin_micro_patch4_window7_56', 64, (2, 2), (2, 4), img_size=56)     # 14x14 -> 7x7 tokens: both shift/no-shift and one merge

@@ -506,22 +506,24 @@ class VisionTransformer(nn.Module):
         return x, FLOPs, global_distance
 
 
-def _factory(embed_dim, depth, num_heads, input_quant=True):
+def _factory(name, embed_dim, depth, num_heads, input_quant=True):
     def make(pretrained=False, quant=False, calibrate=False, cfg=None, **kwargs):
-        if pretrained:
-            raise RuntimeError('pretrained weights are fetched from remote URLs in the reference (vit_fquant.py:822-828);'
-                               ' load a local checkpoint with model.load_state_dict(...) instead')
         if cfg is None:
             from .config import Config
             cfg = Config()
-        return VisionTransformer(patch_size=16, embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=4,
-                                 qkv_bias=True, norm_layer=partial(QIntLayerNorm, eps=1e-6), quant=quant,
-                                 calibrate=calibrate, input_quant=input_quant, cfg=cfg, **kwargs)
+        model = VisionTransformer(patch_size=16, embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=4,
+                                  qkv_bias=True, norm_layer=partial(QIntLayerNorm, eps=1e-6), quant=quant,
+                                  calibrate=calibrate, input_quant=input_quant, cfg=cfg, **kwargs)
+        if pretrained:       # vit_fquant.py:822-828: the checkpoint of the torch-hub cache (never fetched here: checkpoint.load_pretrained)
+            from .checkpoint import load_pretrained
+            load_pretrained(model, name)
+        return model
+    make.__name__ = name
     return make
 
 
-deit_tiny_patch16_224 = _factory(192, 12, 3)
-deit_small_patch16_224 = _factory(384, 12, 6)
-deit_base_patch16_224 = _factory(768, 12, 12)
-vit_base_patch16_224 = _factory(768, 12, 12)
-vit_large_patch16_224 = _factory(1024, 24, 16, input_quant=False)
+deit_tiny_patch16_224 = _factory('deit_tiny_patch16_224', 192, 12, 3)
+deit_small_patch16_224 = _factory('deit_small_patch16_224', 384, 12, 6)
+deit_base_patch16_224 = _factory('deit_base_patch16_224', 768, 12, 12)
+vit_base_patch16_224 = _factory('vit_base_patch16_224', 768, 12, 12)
+vit_large_patch16_224 = _factory('vit_large_patch16_224', 1024, 24, 16, input_quant=False)

@@ -67,3 +67,31 @@ def test_harness_on_an_image_folder(tmp_path, capsys):
     out = capsys.readouterr().out
     assert 'Test: [0/2]' in out and ' * Prec@1' in out
     assert 0.0 <= top1 <= 100.0 and np.isfinite(loss)
+
+
+def test_pretrained_true_reads_the_torch_hub_cache(tmp_path, monkeypatch):
+    """pretrained=True (vit_fquant.py:822-828, test_quant.py:95): the file torch.hub would have downloaded is loaded from
+    <TORCH_HOME>/hub/checkpoints when it is there (.pth under 'model' for DeiT, Flax .npz for ViT-B); a missing file is a
+    FileNotFoundError that names the path - nothing is ever fetched."""
+    import diff_vit_amd as dva
+    from diff_vit_amd import checkpoint as ck
+    monkeypatch.setenv('TORCH_HOME', str(tmp_path))
+    with pytest.raises(FileNotFoundError) as e:
+        dva.deit_tiny_patch16_224(pretrained=True)
+    assert 'deit_tiny_patch16_224-a1311bcf.pth' in str(e.value) and str(tmp_path) in str(e.value)
+    os.makedirs(os.path.join(str(tmp_path), 'hub', 'checkpoints'))
+    arch = dva.synth.ARCHS['deit_tiny']
+    sd = dva.synth.vit_state_dict(arch, 5)
+    torch.save({'model': sd}, ck.pretrained_path('deit_tiny_patch16_224'))
+    m = dva.deit_tiny_patch16_224(pretrained=True)
+    assert all(torch.equal(m.state_dict()[k], v) for k, v in sd.items())
+    # the Flax layout of the ViT-B factory (models/utils.py:12-197)
+    archb = dva.synth.ARCHS['vit_base']
+    sdb = dva.synth.vit_state_dict(archb, 6)
+    np.savez(ck.pretrained_path('vit_base_patch16_224'), **ck.state_dict_to_vit_npz(sdb, archb['depth'], archb['num_heads']))
+    mb = dva.vit_base_patch16_224(pretrained=True)
+    assert all(torch.equal(mb.state_dict()[k], v) for k, v in sdb.items())
+    assert set(ck.PRETRAINED_FILES) >= {'deit_small_patch16_224', 'deit_base_patch16_224', 'vit_large_patch16_224', 'swin_tiny_patch4_window7_224',
+                                        'swin_small_patch4_window7_224', 'swin_base_patch4_window7_224'}
+    with pytest.raises(FileNotFoundError):
+        dva.swin_tiny_patch4_window7_224(pretrained=True)
