@@ -275,7 +275,7 @@ static int run_gemm(int epi, const int8_t* A, int lda, int M, int K, int N, cons
 static int run_ln_gemm(int epi, const LnArgs& a, const p2v_linear& lin, const p2v_epilogue& ep, int N, int8_t* out, hipStream_t st) {
   GemmArgs g;
   if (!lin.w_frag) return fail(P2V_E_UNSUPPORTED, "ln_gemm: the layer has no fragment-order weights (p2v_linear.w_frag)");
-  g.A = nullptr; g.lda = a.C; g.M = (int)a.rows; g.W = lin.w_frag; g.K = round_up(a.C, GBK_PAD); g.N = N; g.w4 = 0;
+  g.A = nullptr; g.lda = a.C; g.M = (int)a.rows; g.W = lin.w_frag; g.K = round_up(a.C, GBK_PAD); g.N = N; g.w4 = lin.packed4 ? 1 : 0;
   g.colscale = lin.colscale; g.bias = lin.bias; g.ep = ep; g.out = out; g.ldo = N; g.out_codes = nullptr; g.tiles_n = 0;
 #ifdef P2V_DIAG
   g.stamps = nullptr;

@@ -1132,6 +1132,12 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
 //   activation panel by the 9 / 12 column-tile workgroups of the tiled kernel.
 // ---------------------------------------------------------------------------------------------------
 #define LG_BM 64
+// W fragments of the fused kernels: 16 bytes per lane (one code per byte) or, for packed int4 weights (p2v_linear.packed4), 8 bytes
+// per lane widened in registers like the tiled kernel's (unpack_w4: codes << 4, the 1/16 goes into the column scale)
+template <bool W4> struct LgW { typedef uint4 raw; };
+template <> struct LgW<true> { typedef uint2 raw; };
+__device__ __forceinline__ v4i lg_wfrag(uint4 w) { return __builtin_bit_cast(v4i, w); }
+__device__ __forceinline__ v4i lg_wfrag(uint2 w) { return unpack_w4(w.x, w.y); }
 struct LnGemmLds {                        // byte offsets inside the dynamic LDS allocation
   int panel, consts, fold, table, total;
 };
@@ -1154,8 +1160,9 @@ __host__ __device__ inline LnGemmLds ln_gemm_lds(int K, int N, int nch, int tabl
 #else
 #define LG_STAMP(slot) do { } while (0)
 #endif
-template <int EPI, int KT>               // KT = k-tiles of 64 channels (C <= 64*KT)
+template <int EPI, int KT, bool W4>      // KT = k-tiles of 64 channels (C <= 64*KT); W4: packed int4 fragment copy
 __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
+  typedef typename LgW<W4>::raw wraw;
   constexpr int NCH = (KT + 1) / 2;      // 128-channel groups of a LayerNorm row
   constexpr int NI = 2 * KT;             // k-steps of 32
   extern __shared__ __attribute__((aligned(1024))) unsigned char lg_smem[];
@@ -1173,10 +1180,10 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
   const int tiles_n = g.tiles_n;
 
   // ---- W fragments of column tile 0 (registers): element ((j*4 + wave)*NI + i)*64 + lane of 16 bytes
-  const uint4* wsrc = reinterpret_cast<const uint4*>(g.W) + (long long)wave * NI * 64 + lane;
-  v4i wf[NI];
+  const wraw* wsrc = reinterpret_cast<const wraw*>(g.W) + (long long)wave * NI * 64 + lane;
+  wraw wf[NI];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) wf[i] = __builtin_bit_cast(v4i, wsrc[i * 64]);
+  for (int i = 0; i < NI; ++i) wf[i] = wsrc[i * 64];
 
   // ---- the 64 rows of the residual stream: one row per half wave, 8 rows each, two rows in flight ahead of the two being normalised
   constexpr int RPH = LG_BM / 8;                                       // rows per half wave
@@ -1197,11 +1204,12 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
   // ---- per-column constants of the whole layer (REQUANT: 2^e folded in, see gemm_stage_epilogue) and the GELU table
   {
     const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : 1.0f;
+    const float cfold = fold * (W4 ? 0.0625f : 1.0f);                   // packed int4: the accumulator holds 16 x the sum
     for (int n4 = tid; n4 < tiles_n * (GBN / 4); n4 += 256) {           // four columns per thread and turn
       const int j_ = n4 >> 5, c_ = (n4 & 31) * 4;
       const float4 cv = *reinterpret_cast<const float4*>(g.colscale + n4 * 4);   // arrays are padded to n_pad
       const float4 bv = *reinterpret_cast<const float4*>(g.bias + n4 * 4);
-      *reinterpret_cast<float4*>(consts + j_ * 2 * GBN + c_) = make_float4(cv.x * fold, cv.y * fold, cv.z * fold, cv.w * fold);
+      *reinterpret_cast<float4*>(consts + j_ * 2 * GBN + c_) = make_float4(cv.x * cfold, cv.y * cfold, cv.z * cfold, cv.w * cfold);
       *reinterpret_cast<float4*>(consts + j_ * 2 * GBN + GBN + c_) = make_float4(bv.x * fold, bv.y * fold, bv.z * fold, bv.w * fold);
     }
     if (EPI == P2V_EPI_GELU_TAB)
@@ -1269,15 +1277,16 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
     const bool more = j + 1 < tiles_n;                                   // wave-uniform
     // the fragment loads are unconditional (the last tile re-requests itself): with a branch around them hipcc cannot count the
     // outstanding requests and waits vmcnt(0) at the top of every tile - i.e. for the output STORES of the tile before
-    const uint4* wnext = wsrc + (long long)(more ? j + 1 : j) * 4 * NI * 64;
+    const wraw* wnext = wsrc + (long long)(more ? j + 1 : j) * 4 * NI * 64;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int off = (i >> 1) * (LG_BM * GBK) + (i & 1) * xks;
       const v4i xa = *reinterpret_cast<const v4i*>(pXa + off);
       const v4i xb = *reinterpret_cast<const v4i*>(pXb + off);
-      acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xa, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xb, acc[1], 0, 0, 0);
-      wf[i] = __builtin_bit_cast(v4i, wnext[i * 64]);                    // the fragment of the next column tile, a tile ahead of its use
+      const v4i wfi = lg_wfrag(wf[i]);
+      acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wfi, xa, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wfi, xb, acc[1], 0, 0, 0);
+      wf[i] = wnext[i * 64];                                             // the fragment of the next column tile, a tile ahead of its use
     }
     LG_STAMP(4 + 2 * j);
     const EpiLds* e = reinterpret_cast<const EpiLds*>(consts + j * 2 * GBN);
@@ -1319,8 +1328,9 @@ __host__ __device__ constexpr int lg2_mfma_at(int hp) {
 
 // EPI: P2V_EPI_REQUANT or P2V_EPI_GELU_TAB;  KT = k-tiles of 64 channels (C <= 64*KT);  NG = wave groups (1: 4 waves, every wave all
 // column tiles, two workgroups per CU; 2: 8 waves, the groups alternate column tiles, one workgroup per CU)
-template <int EPI, int KT, int NG>
+template <int EPI, int KT, int NG, bool W4>
 __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) {
+  typedef typename LgW<W4>::raw wraw;
   constexpr int NT = 256 * NG;           // threads
   static_assert(EPI == P2V_EPI_REQUANT || EPI == P2V_EPI_GELU_TAB, "pipelined epilogues");
   constexpr int NCH = (KT + 1) / 2;      // 128-channel groups of a LayerNorm row
@@ -1342,17 +1352,17 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
   const int n_g = (tiles_n - grp + NG - 1) / NG;                       // column tiles of this group: j = grp + NG*it
 
   // ---- W fragments of the group's first tile (registers): element ((j*4 + cw)*NI + i)*64 + lane of 16 bytes
-  const uint4* wsrc = reinterpret_cast<const uint4*>(g.W) + (long long)cw * NI * 64 + lane;
+  const wraw* wsrc = reinterpret_cast<const wraw*>(g.W) + (long long)cw * NI * 64 + lane;
   auto wtile = [&](int it) {                                           // fragments of the group's it-th tile (clamped: loads are unconditional)
     int j = grp + NG * it;
     j = j < tiles_n ? j : tiles_n - 1;
     return wsrc + (long long)j * 4 * NI * 64;
   };
-  v4i wf[NI];
+  wraw wf[NI];
   {
-    const uint4* w0 = wtile(0);
+    const wraw* w0 = wtile(0);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wf[i] = __builtin_bit_cast(v4i, w0[i * 64]);
+    for (int i = 0; i < NI; ++i) wf[i] = w0[i * 64];
   }
 
   // ---- the 64 rows of the residual stream: one row per half wave, 4 rows each, the second pair in flight while the first is normalised
@@ -1380,11 +1390,12 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
   // ---- per-column constants of the whole layer (REQUANT: 2^e folded in, see gemm_stage_epilogue) and the GELU table
   {
     const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : 1.0f;
+    const float cfold = fold * (W4 ? 0.0625f : 1.0f);                   // packed int4: the accumulator holds 16 x the sum
     for (int n4 = tid; n4 < tiles_n * (GBN / 4); n4 += NT) {           // four columns per thread and turn
       const int j_ = n4 >> 5, c_ = (n4 & 31) * 4;
       const float4 cv = *reinterpret_cast<const float4*>(g.colscale + n4 * 4);   // arrays are padded to n_pad
       const float4 bv = *reinterpret_cast<const float4*>(g.bias + n4 * 4);
-      *reinterpret_cast<float4*>(consts + j_ * 2 * GBN + c_) = make_float4(cv.x * fold, cv.y * fold, cv.z * fold, cv.w * fold);
+      *reinterpret_cast<float4*>(consts + j_ * 2 * GBN + c_) = make_float4(cv.x * cfold, cv.y * cfold, cv.z * cfold, cv.w * cfold);
       *reinterpret_cast<float4*>(consts + j_ * 2 * GBN + GBN + c_) = make_float4(bv.x * fold, bv.y * fold, bv.z * fold, bv.w * fold);
     }
     if (EPI == P2V_EPI_GELU_TAB)
@@ -1451,14 +1462,15 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
     for (int r = 0; r < 16; ++r) acc[b][r] = 0;
   // ---- the group's first tile: plain k-loop (nothing to overlap with), W fragments of its second tile requested behind the MFMAs
   {
-    const uint4* wn = wtile(1);
+    const wraw* wn = wtile(1);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const v4i xa = *reinterpret_cast<const v4i*>(pXa + LG2_XOFF(i));
       const v4i xb = *reinterpret_cast<const v4i*>(pXb + LG2_XOFF(i));
-      acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xa, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i], xb, acc[1], 0, 0, 0);
-      wf[i] = __builtin_bit_cast(v4i, wn[i * 64]);
+      const v4i wfi = lg_wfrag(wf[i]);
+      acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wfi, xa, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wfi, xb, acc[1], 0, 0, 0);
+      wf[i] = wn[i * 64];
     }
   }
   LG_STAMP(4);
@@ -1473,7 +1485,8 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
   // One column tile: the epilogue of acc (tile j) in 24 half-pieces; with MF the 2*NI MFMAs of the group's next tile are issued
   // one per half-piece into accn (X fragments one k-step ahead); with LD the W fragment of the tile after next replaces the one
   // an MFMA pair has just consumed.
-  auto tile_body = [&](auto MFc, auto LDc, int j, const uint4* wnn) {
+  v4i wcur = {0, 0, 0, 0};                                               // the widened fragment between the two MFMAs of a k-step
+  auto tile_body = [&](auto MFc, auto LDc, int j, const wraw* wnn) {
     constexpr bool MF = decltype(MFc)::value, LD = decltype(LDc)::value;
     const float* cst = consts + j * 2 * GBN + 32 * cw + 4 * h;           // colscale of this wave's columns; bias at + GBN
     const int n_tile = j * GBN + 32 * cw;
@@ -1486,13 +1499,14 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
         constexpr int i_ = q_ >> 1, nx_ = (i_ + 1) % NI;                                                                 \
         if constexpr ((q_ & 1) == 0) {                                                                                   \
           XA[nx_ & 1] = *reinterpret_cast<const v4i*>(pXa + LG2_XOFF(nx_));                                              \
-          if constexpr (i_ == 0) accn[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i_], XA[i_ & 1], (v16i){0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, 0, 0, 0); \
-          else accn[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i_], XA[i_ & 1], accn[0], 0, 0, 0);                    \
+          wcur = lg_wfrag(wf[i_]);                                                                                       \
+          if constexpr (i_ == 0) accn[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wcur, XA[i_ & 1], (v16i){0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, 0, 0, 0); \
+          else accn[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wcur, XA[i_ & 1], accn[0], 0, 0, 0);                      \
         } else {                                                                                                         \
           XB[nx_ & 1] = *reinterpret_cast<const v4i*>(pXb + LG2_XOFF(nx_));                                              \
-          if constexpr (i_ == 0) accn[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i_], XB[i_ & 1], (v16i){0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, 0, 0, 0); \
-          else accn[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[i_], XB[i_ & 1], accn[1], 0, 0, 0);                    \
-          if constexpr (LD) wf[i_] = __builtin_bit_cast(v4i, wnn[i_ * 64]);                                              \
+          if constexpr (i_ == 0) accn[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wcur, XB[i_ & 1], (v16i){0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, 0, 0, 0); \
+          else accn[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wcur, XB[i_ & 1], accn[1], 0, 0, 0);                      \
+          if constexpr (LD) wf[i_] = wnn[i_ * 64];                                                                       \
         }                                                                                                                \
       }                                                                                                                  \
     } while (0)
@@ -2269,30 +2283,34 @@ bool p2v_ln_gemm_supported(int epi, int C, int N, int table_cells) {
   if (C % 4 || C > 384 || N % 16) return false;
   return ln_gemm_lds(C, N, ((C + GBK - 1) / GBK + 1) / 2, table_cells).total <= 80 * 1024;     // two workgroups per CU
 }
-template <int EPI, int KT, int VER>
-static int launch_ln_gemm_t(const LnArgs& a, const GemmArgs& g, int cells, hipStream_t st) {
+template <int EPI, int KT, int VER, bool W4>
+static int launch_ln_gemm_t2(const LnArgs& a, const GemmArgs& g, int cells, hipStream_t st) {
   const int smem = ln_gemm_lds(a.C, g.N, (KT + 1) / 2, cells).total;
   static int granted[16] = {0};                 // per device: the dynamic LDS size this instantiation has been allowed so far
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
   const void* fn;
-  if constexpr (VER == 3) fn = reinterpret_cast<const void*>(&k_ln_gemm2<EPI, KT, 2>);
-  else if constexpr (VER == 2) fn = reinterpret_cast<const void*>(&k_ln_gemm2<EPI, KT, 1>);
-  else fn = reinterpret_cast<const void*>(&k_ln_gemm<EPI, KT>);
+  if constexpr (VER == 3) fn = reinterpret_cast<const void*>(&k_ln_gemm2<EPI, KT, 2, W4>);
+  else if constexpr (VER == 2) fn = reinterpret_cast<const void*>(&k_ln_gemm2<EPI, KT, 1, W4>);
+  else fn = reinterpret_cast<const void*>(&k_ln_gemm<EPI, KT, W4>);
   if (dev < 0 || smem > granted[dev]) {         // (a racing second thread only repeats the call)
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     if (dev >= 0) granted[dev] = smem;
   }
   const dim3 grid((unsigned)((g.M + LG_BM - 1) / LG_BM));
-  if constexpr (VER == 3) hipLaunchKernelGGL((k_ln_gemm2<EPI, KT, 2>), grid, dim3(512), (unsigned)smem, st, a, g);
-  else if constexpr (VER == 2) hipLaunchKernelGGL((k_ln_gemm2<EPI, KT, 1>), grid, dim3(256), (unsigned)smem, st, a, g);
-  else hipLaunchKernelGGL((k_ln_gemm<EPI, KT>), grid, dim3(256), (unsigned)smem, st, a, g);
+  if constexpr (VER == 3) hipLaunchKernelGGL((k_ln_gemm2<EPI, KT, 2, W4>), grid, dim3(512), (unsigned)smem, st, a, g);
+  else if constexpr (VER == 2) hipLaunchKernelGGL((k_ln_gemm2<EPI, KT, 1, W4>), grid, dim3(256), (unsigned)smem, st, a, g);
+  else hipLaunchKernelGGL((k_ln_gemm<EPI, KT, W4>), grid, dim3(256), (unsigned)smem, st, a, g);
   CHECK_LAUNCH();
   return 0;
 }
+template <int EPI, int KT, int VER>
+static int launch_ln_gemm_t(const LnArgs& a, const GemmArgs& g, int cells, hipStream_t st) {
+  return g.w4 ? launch_ln_gemm_t2<EPI, KT, VER, true>(a, g, cells, st) : launch_ln_gemm_t2<EPI, KT, VER, false>(a, g, cells, st);
+}
 int g_ln_gemm_ver = 2;    // P2V_LN_GEMM_V=1: the 4-wave kernel of round 2 for every launch (A/B runs; same results)
-// g0.W must point to the FRAGMENT-ORDER copy of the weights (p2v_linear.w_frag)
+// g0.W must point to the FRAGMENT-ORDER copy of the weights (p2v_linear.w_frag; packed two codes per byte when g0.w4)
 int p2v_launch_ln_gemm(int epi, const LnArgs& a_, const GemmArgs& g0, hipStream_t st) {
   const int cells = (epi == P2V_EPI_GELU && g0.ep.gelu.table) ? g0.ep.gelu.cells : 0;
   if (!p2v_ln_gemm_supported(epi, a_.C, g0.N, cells)) return -3;

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libp2vit_hip.so')
 
-P2V_ABI_VERSION = 3
+P2V_ABI_VERSION = 4
 EPI_REQUANT, EPI_GELU, EPI_RESID, EPI_EMBED, EPI_HEAD = 0, 1, 2, 3, 4
 E_ARG, E_BITS, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH, E_STATE = -1, -2, -3, -4, -5, -6, -7
 
@@ -189,6 +189,18 @@ def fragment_order(wp):
     n_pad, k_pad = wp.shape
     assert n_pad % 128 == 0 and k_pad % 64 == 0
     return wp.reshape(n_pad // 128, 4, 32, k_pad // 32, 2, 16).permute(0, 1, 3, 4, 2, 5).contiguous()
+
+
+def fragment_order_packed4(wp):
+    """4-bit codes in [-8, 7], [n_pad][k_pad] -> ``p2v_linear.w_frag`` for ``packed4`` layers: the fragment order of
+    :func:`fragment_order` with the 16 codes of a lane in 8 bytes (byte j of dword 0 = code[j] | code[4+j] << 4, of dword 1 =
+    code[8+j] | code[12+j] << 4: the chunk format of :func:`pack_int4_tiles`); uint8 [.., 64 lanes, 8]."""
+    import torch
+    assert int(wp.min()) >= -8 and int(wp.max()) <= 7
+    f = (fragment_order(wp).to(torch.int16) & 15).to(torch.uint8)              # [tile, wave, kstep, h, r, 16]
+    lo = f[..., [0, 1, 2, 3, 8, 9, 10, 11]]
+    hi = f[..., [4, 5, 6, 7, 12, 13, 14, 15]]
+    return (lo | (hi << 4)).contiguous()
 
 
 def pack_int4_tiles(wp):

@@ -228,8 +228,10 @@ class FrozenPlan:
             bp[:N] = bias
             # qkv / fc1 follow a LayerNorm: a second copy in MFMA-fragment order feeds the fused LayerNorm+GEMM kernel
             wdev = self._dev(E.pack_int4_tiles(wp), torch.uint8) if bits == 4 else self._dev(wp, torch.int8)
-            lin = E.Linear(E.ptr(wdev), E.ptr(self._dev(cs_col)), E.ptr(self._dev(bp)),
-                           E.ptr(self._dev(E.fragment_order(wp), torch.int8)) if self.D <= 384 else None, 1 if bits == 4 else 0)
+            frag = None
+            if self.D <= 384:        # 4-bit layers: the fragment copy travels packed too (two codes per byte, ABI 4)
+                frag = E.ptr(self._dev(E.fragment_order_packed4(wp), torch.uint8) if bits == 4 else self._dev(E.fragment_order(wp), torch.int8))
+            lin = E.Linear(E.ptr(wdev), E.ptr(self._dev(cs_col)), E.ptr(self._dev(bp)), frag, 1 if bits == 4 else 0)
             E.check(L.p2v_plan_set_linear(self._handle, layer, bits, C.byref(lin)))
 
     # ---------------------------------------------------------------------------------------------

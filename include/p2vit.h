@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define P2V_ABI_VERSION 3
+#define P2V_ABI_VERSION 4
 #define P2V_MAX_TOKENS 608   /* tokens per image of the ViT attention kernel (19 pairs of 32 keys) */
 
 enum {
@@ -87,7 +87,9 @@ typedef struct p2v_linear {
   const int8_t* w_frag;  /* dev, optional (NULL): the same codes in MFMA-fragment order for p2v_ln_gemm_i8 --
                           * [n_pad/128 column tiles][4 waves][k_pad/32 k-steps][64 lanes][16 bytes], lane = 32*h + r holding
                           * W[128*tile + 32*wave + r][32*kstep + 16*h .. +16): the A operand of v_mfma_i32_32x32x32_i8 as one
-                          * coalesced 1 KB load per wave (always one code per byte) */
+                          * coalesced 1 KB load per wave.  packed4 == 0: one code per byte (16 bytes per lane).  packed4 == 1 (ABI 4):
+                          * the lane's 16 codes in 8 bytes, byte j of dword 0 = code[j] | code[4+j] << 4, of dword 1 =
+                          * code[8+j] | code[12+j] << 4 (the chunk format of the packed tiles): half the weight bytes */
   int32_t packed4;       /* 1: w_codes is the packed int4 tile layout described above */
 } p2v_linear;
 

@@ -185,3 +185,10 @@ def test_int4_tile_packing_layout():
     assert c0 == 0
     assert np.array_equal(even[:4], 16 * wn[5, 0:4]) and np.array_equal(odd[:4], 16 * wn[5, 4:8])
     assert np.array_equal(even[4:], 16 * wn[5, 8:12]) and np.array_equal(odd[4:], 16 * wn[5, 12:16])
+    # the packed FRAGMENT-order copy of the fused LayerNorm+GEMM kernels (p2v_linear.w_frag with packed4 = 1, ABI 4)
+    f = dva.engine.fragment_order_packed4(w).numpy()
+    assert f.shape == (2, 4, 4, 2, 32, 8) and f.dtype == np.uint8
+    for (t, wave, ks, h, r, j) in ((0, 0, 0, 0, 0, 0), (1, 3, 3, 1, 31, 7), (0, 2, 1, 1, 9, 5), (1, 1, 2, 0, 17, 3)):
+        row, k0 = 128 * t + 32 * wave + r, 32 * ks + 16 * h
+        lo_k, hi_k = (k0 + j, k0 + 4 + j) if j < 4 else (k0 + 8 + (j - 4), k0 + 12 + (j - 4))
+        assert f[t, wave, ks, h, r, j] == ((wn[row, lo_k] & 15) | ((wn[row, hi_k] & 15) << 4)), (t, wave, ks, h, r, j)

@@ -1120,3 +1120,52 @@ def test_gemm_256_row_tiles_equal_128_row_tiles(dva, oracle, M, K, N):
     ref = torch.clamp(torch.round((res * s_res + q3 * s_mid) / s_next), -128, 127)
     assert torch.equal(outs[(256, 'w8', 'resid')].float(), ref)
     assert torch.equal(outs[(128, 'w8', 'gelu')], outs[(128, 'w8', 'gelu_tab')])
+
+
+@pytest.mark.parametrize('C_,N,M,kind', [(384, 1152, 333, 'requant'), (384, 1536, 200, 'gelu'), (192, 576, 130, 'requant'), (64, 256, 70, 'gelu')])
+def test_ln_gemm_packed_int4_fragments(dva, oracle, C_, N, M, kind):
+    """4-bit layers of the fused LayerNorm+GEMM kernels stream PACKED fragment-order weights (two codes per byte, ABI 4: p2v_linear.w_frag with
+    packed4 = 1): every kernel version gives the bytes of p2v_int_layernorm + p2v_gemm_i8 on the packed tiles and of the unpacked fragment copy."""
+    E, S = dva.engine, dva.synth
+    L = E.lib()
+    tag = 'p%d_%d' % (C_, N)
+    codes = _rand_codes(S, 17, tag + 'x', (M, C_), 35.0)
+    in_scale = 0.0123 * 2.0 ** torch.floor(S.uniform(17, tag + 'm', (C_,), 0, 3.99))
+    gamma = S.uniform(17, tag + 'g', (C_,), -1.5, 1.5); beta = S.normal(17, tag + 'b', (C_,), 0.3)
+    cs = 2.0 ** torch.floor(S.uniform(17, tag + 'c', (C_,), -2, 2.99))
+    s_a = 2.0 ** -4
+    out_scale = s_a * cs
+    s1 = in_scale.min()
+    k_pad, n_pad = (C_ + 63) // 64 * 64, (N + 127) // 128 * 128
+    w = torch.clamp(torch.round(_rand_codes(S, 17, tag + 'w', (N, C_), 30.0) / 12.0), -8, 7)
+    wp = torch.zeros(n_pad, k_pad, dtype=torch.int8); wp[:N, :C_] = w.to(torch.int8)
+    s_w = torch.full((N,), 2.0 ** -4); s_w[::3] = 2.0 ** -3
+    csl = torch.zeros(n_pad); csl[:N] = s_a * s_w
+    bp = torch.zeros(n_pad); bp[:N] = S.normal(17, tag + 'bb', (N,), 0.4)
+    d = [t.contiguous().cuda() for t in (codes.to(torch.int8), torch.round(in_scale / s1), gamma, beta, 1.0 / out_scale, torch.ones(C_), csl, bp)]
+    lnp = E.Ln(float(s1), *[E.ptr(t) for t in d[1:6]])
+    tiles4 = E.pack_int4_tiles(wp).cuda(); frag4 = E.fragment_order_packed4(wp).cuda()
+    w8 = wp.cuda(); frag8 = E.fragment_order(wp).cuda()
+    lin4 = E.Linear(E.ptr(tiles4), E.ptr(d[6]), E.ptr(d[7]), E.ptr(frag4), 1)
+    lin8 = E.Linear(E.ptr(w8), E.ptr(d[6]), E.ptr(d[7]), E.ptr(frag8), 0)
+    epi = E.Epilogue()
+    s_out = 2.0 ** -3 if kind == 'requant' else 2.0 ** -5
+    epi.inv_s_out = 1.0 / s_out
+    ek = E.EPI_REQUANT if kind == 'requant' else E.EPI_GELU
+    if kind == 'gelu':
+        epi.gelu = E.gelu_table(1.0 / s_out, 'cuda')
+    ln_sep = torch.zeros(M, k_pad, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_int_layernorm(E.ptr(d[0]), C_, M, C_, C.byref(lnp), E.ptr(ln_sep), k_pad, E.stream_ptr()))
+    out_sep = torch.zeros(M, N, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_gemm_i8(ek, E.ptr(ln_sep), k_pad, M, k_pad, N, C.byref(lin4), C.byref(epi), E.ptr(out_sep), N, None, E.stream_ptr()))
+    try:
+        for ver in (1, 3, 2):
+            E.check(L.p2v_set_tuning(b'ln_gemm_version', ver))
+            for lin in (lin4, lin8):
+                out_v = torch.full((M, N), 77, dtype=torch.int8, device='cuda')
+                E.check(L.p2v_ln_gemm_i8(ek, E.ptr(d[0]), C_, M, C_, C.byref(lnp), N, C.byref(lin), C.byref(epi), E.ptr(out_v), N, None, E.stream_ptr()))
+                torch.cuda.synchronize()
+                assert torch.equal(out_v, out_sep), (ver, lin.packed4, int((out_v != out_sep).sum()))
+    finally:
+        E.check(L.p2v_set_tuning(b'ln_gemm_version', 2))
+    assert len(torch.unique(out_sep)) > 20
