@@ -330,11 +330,22 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
   } while (0)
 
   // qact_input + PatchEmbed + cls/pos/qact1                                 vit_fquant.py:705-733
-  STEP(P2V_K_PATCHIFY, launch_rc(p2v_launch_patchify(images, batch, d.in_chans, d.img_size, d.img_size, d.patch_size, p->inv_s_input, bufP,
-                                     p->k_patch_pad, st), "quantize_patchify"));
-  {
+  if (p->inv_s_input > 0.f) {
+    STEP(P2V_K_PATCHIFY, launch_rc(p2v_launch_patchify(images, batch, d.in_chans, d.img_size, d.img_size, d.patch_size, p->inv_s_input, bufP,
+                                       p->k_patch_pad, st), "quantize_patchify"));
     const p2v_linear& l = p->lin[bit_index(bit_config[0])][0];
     STEP(P2V_K_GEMM_EMBED, run_gemm(P2V_EPI_EMBED, bufP, p->k_patch_pad, batch * p->patches, p->k_patch_pad, D, l, p->embed_epi, bufX, D, nullptr, st));
+  } else {
+    // input_quant = False (vit_fquant.py:705, the vit_large factory :925): the fp32 image feeds the fake-quantised convolution
+    const p2v_linear& l = p->lin[bit_index(bit_config[0])][0];
+    if (l.packed4) return fail(P2V_E_UNSUPPORTED, "input_quant = False: the patch-embed weights must be unpacked codes (packed4 = 0)");
+    GemmArgs g;
+    g.A = nullptr; g.lda = 0; g.M = batch * p->patches; g.W = l.w_codes; g.K = p->k_patch_pad; g.N = D; g.w4 = 0;
+    g.colscale = l.colscale; g.bias = l.bias; g.ep = p->embed_epi; g.out = bufX; g.ldo = D; g.out_codes = nullptr; g.tiles_n = 0;
+#ifdef P2V_DIAG
+    g.stamps = nullptr;
+#endif
+    STEP(P2V_K_GEMM_EMBED, launch_rc(p2v_launch_embed_fp32(images, batch, d.in_chans, d.img_size, d.img_size, d.patch_size, g, st), "embed_fp32"));
   }
   STEP(P2V_K_FILL_CLS, launch_rc(p2v_launch_fill_cls(bufX, batch, T, D, p->cls_codes, st), "fill_cls"));
 

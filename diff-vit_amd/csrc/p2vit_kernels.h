@@ -62,6 +62,8 @@ int p2v_launch_window_attention(const WinAttnArgs& a, hipStream_t st);
 
 int p2v_launch_patchify(const float* img, int B, int C, int H, int W, int P, float inv_s, int8_t* out, int k_pad, hipStream_t st);
 int p2v_launch_fill_cls(int8_t* x, int B, int T, int D, const int8_t* cls, hipStream_t st);
+// fp32 image x fake-quantised conv weights (input_quant = False): EMBED epilogue, g.A unused, g.W unpacked int8 codes [n_pad][K]
+int p2v_launch_embed_fp32(const float* img, int B, int C, int H, int W, int P, const GemmArgs& g, hipStream_t st);
 int p2v_launch_gemm(int epi, const GemmArgs& g, hipStream_t st);
 int p2v_launch_layernorm(const LnArgs& a, hipStream_t st);
 bool p2v_ln_gemm_supported(int epi, int C, int N, int table_cells);

@@ -627,6 +627,78 @@ __global__ __launch_bounds__(512, 4) void k_gemm_i8(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K1f: patch embedding of an UN-quantised image (VisionTransformer(input_quant=False): the reference's vit_large factory,
+//   vit_fquant.py:925, 705-706): the fp32 pixels go straight into the QConv2d, whose weights are fake-quantised (layers.py:82-88):
+//   y = F.conv2d(x, code_w * s_w, bias).  Not an integer contraction - canonical reading: the sum of the
+//   products x * code_w in fp64 (every product is exact there; 24 + 8 bits), times the power-of-two s_w, plus the bias, rounded to fp32
+//   ONCE; then the EMBED chain of gemm_epilogue_tile.  One launch per forward (39.5 G fp64 FMAs per 256 ViT-L images, ~2 % of the
+//   step); 64 x 64 output tile, 4 x 4 outputs per thread, k-tiles of 16 straight from the image (im2col folded into the addressing).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_embed_fp32(const float* __restrict__ img, int B, int Cin, int H, int Wd, int P, GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float sX[16][68], sW[16][68];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int gw = Wd / P, gh = H / P, patches = gw * gh;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int K = Cin * P * P;
+  // loader role: row lr of the tile, 4 consecutive k
+  const int lr = tid >> 2, lk = (tid & 3) * 4;
+  int mrow = m0 + lr;
+  mrow = mrow < g.M ? mrow : g.M - 1;
+  const int b_ = mrow / patches, pr = mrow % patches, py = pr / gw, px = pr % gw;
+  const float* ibase = img + (long long)b_ * Cin * H * Wd + (long long)py * P * Wd + px * P;
+  const int8_t* wbase = g.W + (long long)(n0 + lr) * g.K + lk;           // rows padded to n_pad, zero beyond N
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const int k = k0 + lk;
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned wv = 0;
+    if (k < K) {                                                          // K is a multiple of 4 (patch_size % 4 == 0)
+      const int c = k / (P * P), rem = k % (P * P), i = rem / P, j = rem % P;
+      xv = *reinterpret_cast<const float4*>(ibase + ((long long)c * H + i) * Wd + j);
+      wv = *reinterpret_cast<const unsigned*>(wbase + k0);
+    }
+    __syncthreads();
+    sX[lk + 0][lr] = xv.x; sX[lk + 1][lr] = xv.y; sX[lk + 2][lr] = xv.z; sX[lk + 3][lr] = xv.w;
+    sW[lk + 0][lr] = (float)sx8(wv, 0); sW[lk + 1][lr] = (float)sx8(wv, 1); sW[lk + 2][lr] = (float)sx8(wv, 2); sW[lk + 3][lr] = (float)sx8(wv, 3);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float4 xa = *reinterpret_cast<const float4*>(&sX[kk][ty * 4]);
+      const float4 wa = *reinterpret_cast<const float4*>(&sW[kk][tx * 4]);
+      const double xd[4] = {(double)xa.x, (double)xa.y, (double)xa.z, (double)xa.w};
+      const double wd[4] = {(double)wa.x, (double)wa.y, (double)wa.z, (double)wa.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(xd[i], wd[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= g.M) continue;
+    const int bb = m / patches, tok = m % patches + 1;
+    const long long out_row = (long long)bb * (patches + 1) + tok;
+    const int n = n0 + tx * 4;
+    if (n >= g.N) continue;                                               // N is a multiple of 4
+    float q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float y = (float)__builtin_fma(acc[i][j], (double)g.colscale[n + j], (double)g.bias[n + j]);   // ONE rounding
+      const float q1 = sat8f(y * g.ep.inv_s_pe);                          // PatchEmbed.qact
+      const float q2 = sat8f(q1 * g.ep.pe_to_embed);                      // qact_embed (both PoT: exact ratio)
+      const float xs = __builtin_fmaf(q2, g.ep.s_embed, g.ep.pos_deq[(long long)tok * g.N + n + j]);   // + qact_pos(pos_embed)
+      q[j] = rintf(xs / g.ep.s_next[n + j]);                              // qact1 (PTF): IEEE division like the reference
+    }
+    *reinterpret_cast<unsigned*>(reinterpret_cast<int8_t*>(g.out) + out_row * g.ldo + n) = pack4_sat(q[0], q[1], q[2], q[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K1d: the tiled GEMM with LDS-DMA staging (global_load_lds_dwordx4, gfx950).
 //   Why: in the register-staged round-1 kernel (removed) every k-tile moved 16 KB global -> VGPR -> ds_write_b128 -> LDS.  ds_write_b128 sustains ~79 B/clk per
 //   CU (13 cycles per wave-instruction), i.e. ~207 cycles of the CU's one LDS store path per workgroup and k-tile; with three
@@ -2169,6 +2241,14 @@ int p2v_launch_patchify(const float* img, int B, int C, int H, int W, int P, flo
   const int rows_per_block = 8;
   hipLaunchKernelGGL(k_quantize_patchify, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st, img, B, C, H, W, P,
                      inv_s, out, k_pad, rows_per_block);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int p2v_launch_embed_fp32(const float* img, int B, int C, int H, int W, int P, const GemmArgs& g, hipStream_t st) {
+  if (g.w4 || g.N % 4 || P % 4) return -1;
+  const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64));
+  hipLaunchKernelGGL(k_embed_fp32, grid, dim3(256), 0, st, img, B, C, H, W, P, g);
   CHECK_LAUNCH();
   return 0;
 }

@@ -56,8 +56,9 @@ def lis_consts(sf):
 class FrozenPlan:
     """Device-resident integer plan + handle of the C plan object."""
 
-    def __init__(self, arch, state_dict, calib, device='cuda', in_chans=3):
+    def __init__(self, arch, state_dict, calib, device='cuda', in_chans=3, input_quant=True):
         self.arch = dict(arch)
+        self.input_quant = bool(input_quant)      # False: the fp32 image feeds the patch-embed convolution (vit_fquant.py:705, :925)
         self.device = torch.device(device)
         if self.device.type == 'cuda' and self.device.index is None:
             self.device = torch.device('cuda', torch.cuda.current_device())
@@ -92,8 +93,9 @@ class FrozenPlan:
         self._keep.append(t)
         return t
 
-    def _linear(self, layer, w, cs, s_x, dic, bias):
-        """QLinear/QConv2d weight for both bit widths (layers.py:173-178; uniform.py:82-88)."""
+    def _linear(self, layer, w, cs, s_x, dic, bias, pack4=True):
+        """QLinear/QConv2d weight for both bit widths (layers.py:173-178; uniform.py:82-88).  ``pack4`` False keeps 4-bit codes one
+        per byte (the fp32-input patch embedding reads unpacked codes)."""
         L = E.lib()
         w2 = w.reshape(w.shape[0], -1)
         if cs is not None:
@@ -114,8 +116,9 @@ class FrozenPlan:
             if bias is not None:
                 bp[:N] = bias
             # 4-bit weights travel packed, two codes per byte (half the HBM bytes of BASELINE config 5), as LDS tile images
-            wdev = self._dev(E.pack_int4_tiles(wp), torch.uint8) if bits == 4 else self._dev(wp, torch.int8)
-            lin = E.Linear(E.ptr(wdev), E.ptr(self._dev(cs_col)), E.ptr(self._dev(bp)), None, 1 if bits == 4 else 0)
+            packed = bits == 4 and pack4
+            wdev = self._dev(E.pack_int4_tiles(wp), torch.uint8) if packed else self._dev(wp, torch.int8)
+            lin = E.Linear(E.ptr(wdev), E.ptr(self._dev(cs_col)), E.ptr(self._dev(bp)), None, 1 if packed else 0)
             E.check(L.p2v_plan_set_linear(self._handle, layer, bits, C.byref(lin)))
 
     def _ln(self, in_scale, gamma, beta, out_scale, post_mul):
@@ -137,8 +140,12 @@ class FrozenPlan:
         a, D = self.arch, self.D
         hd = D // self.H
         # ---- stem ------------------------------------------------------------------------------
-        s_in = _need_pot('qact_input', c['qact_input'])
-        self._linear(0, W['patch_embed.proj.weight'], None, s_in, c['patch_embed.proj'], W['patch_embed.proj.bias'])
+        if self.input_quant:
+            s_in = _need_pot('qact_input', c['qact_input'])
+            self._linear(0, W['patch_embed.proj.weight'], None, s_in, c['patch_embed.proj'], W['patch_embed.proj.bias'])
+        else:      # no input QAct: colscale = s_w, unpacked codes; p2v_plan_set_embed(inv_s_input = 0) selects the fp32-image kernel
+            s_in = torch.ones(1)
+            self._linear(0, W['patch_embed.proj.weight'], None, s_in, c['patch_embed.proj'], W['patch_embed.proj.bias'], pack4=False)
         s_pe = _need_pot('patch_embed.qact', c['patch_embed.qact'])
         s_e = _need_pot('qact_embed', c['qact_embed'])
         s_p = _need_pot('qact_pos', c['qact_pos'])
@@ -153,7 +160,8 @@ class FrozenPlan:
         epi.s_next = E.ptr(self._dev(s_res))
         epi.pos_deq = E.ptr(self._dev(pos_deq))
         epi.patches = self.patches
-        E.check(L.p2v_plan_set_embed(self._handle, float(1.0 / s_in), C.byref(epi), E.ptr(self._dev(cls_codes, torch.int8))))
+        E.check(L.p2v_plan_set_embed(self._handle, float(1.0 / s_in) if self.input_quant else 0.0, C.byref(epi),
+                                     E.ptr(self._dev(cls_codes, torch.int8))))
         # ---- blocks ----------------------------------------------------------------------------
         for i in range(self.depth):
             p = 'blocks.%d.' % i

@@ -383,10 +383,6 @@ class VisionTransformer(nn.Module):
     # ---- frozen integer plan -----------------------------------------------------------------------------------
     def export_calib(self):
         """calibration state in the nested-dict format of ``plan.FrozenPlan`` / ``calib_io``."""
-        if not self.input_quant:
-            raise NotImplementedError('input_quant=False (the reference\'s vit_large factory, vit_fquant.py:925) feeds the fp32 image to the '
-                                      'patch-embed convolution: not an integer pipeline, not part of the fused engine')
-
         def sc(q):
             if q.quantizer.scale is None:
                 raise RuntimeError('the model has not been calibrated: run the calibration sequence (harness.calibrate_model) before a quantized forward')
@@ -395,10 +391,12 @@ class VisionTransformer(nn.Module):
         def dic(l):
             return {k: v.detach().float().cpu() for k, v in l.quantizer.dic_scale.items()}
 
-        c = {'qact_input': sc(self.qact_input), 'patch_embed.proj': dic(self.patch_embed.proj),
+        c = {'patch_embed.proj': dic(self.patch_embed.proj),
              'patch_embed.qact': sc(self.patch_embed.qact), 'qact_embed': sc(self.qact_embed),
              'qact_pos': sc(self.qact_pos), 'qact1': sc(self.qact1), 'qact2': sc(self.qact2), 'head': dic(self.head),
              'act_out': sc(self.act_out)}
+        if self.input_quant:       # input_quant=False (the reference's vit_large factory, vit_fquant.py:925): no input QAct to export
+            c['qact_input'] = sc(self.qact_input)
         for i, blk in enumerate(self.blocks):
             p = 'blocks.%d.' % i
             for nm, m in ((p + 'attn', blk.attn), (p + 'mlp', blk.mlp)):
@@ -420,13 +418,11 @@ class VisionTransformer(nn.Module):
     def freeze(self, device=None):
         """build (once) the integer plan the HIP engine executes; called lazily by the first quantized forward."""
         from .plan import FrozenPlan
-        if not self.input_quant:
-            raise NotImplementedError('the HIP engine fuses qact_input into the patch gather: input_quant=True models only')
         if not (self.cfg.INT_NORM and self.cfg.INT_SOFTMAX):
             raise NotImplementedError('the HIP engine implements the ptf=True, lis=True configuration')
         dev = device or self.cls_token.device
         sd = {k: v for k, v in self.state_dict().items()}
-        self._plan = FrozenPlan(self.arch, sd, self.export_calib(), device=dev, in_chans=self.in_chans)
+        self._plan = FrozenPlan(self.arch, sd, self.export_calib(), device=dev, in_chans=self.in_chans, input_quant=self.input_quant)
         return self._plan
 
     def flops(self):

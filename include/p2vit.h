@@ -162,7 +162,10 @@ void p2v_plan_destroy(p2v_plan* plan);
  * 0 = patch embed, 1+4*i+{0,1,2,3} = block i {qkv, proj, fc1, fc2}, 4*depth+1 = head.  bits in {4,8}. */
 int p2v_plan_set_linear(p2v_plan* plan, int layer, int bits, const p2v_linear* lin);
 
-/* qact_input scale; embed epilogue constants (one set per patch-embed bit width index 0:4-bit 1:8-bit is not
+/* inv_s_input = 1 / qact_input scale; inv_s_input == 0 selects VisionTransformer(input_quant=False) (the reference's vit_large
+ * factory, vit_fquant.py:925): no input QAct, the fp32 image feeds the fake-quantised convolution directly - fp64 accumulation of the
+ * exact products, one rounding to fp32; the layer-0 weights must then be unpacked codes (packed4 = 0) with colscale = s_w.
+ * embed epilogue constants (one set per patch-embed bit width index 0:4-bit 1:8-bit is not
  * needed: activation scales do not depend on the weight bits); cls row codes [D] after qact1. */
 int p2v_plan_set_embed(p2v_plan* plan, float inv_s_input, const p2v_epilogue* embed_epi,
                        const int8_t* cls_row_codes /* dev [D] */);

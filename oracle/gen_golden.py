@@ -50,7 +50,7 @@ def build_ref(arch, sd, ref):
         img_size=arch['img_size'], patch_size=arch['patch_size'], embed_dim=arch['embed_dim'],
         depth=arch['depth'], num_heads=arch['num_heads'], num_classes=arch['num_classes'],
         mlp_ratio=arch['mlp_ratio'], qkv_bias=True,
-        norm_layer=partial(ref_models.QIntLayerNorm, eps=1e-6), input_quant=True, cfg=cfg)
+        norm_layer=partial(ref_models.QIntLayerNorm, eps=1e-6), input_quant=arch.get('input_quant', True), cfg=cfg)
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and not missing, (missing, unexpected)
     m.eval()
@@ -297,6 +297,9 @@ def main():
         gen_kat(ref)
     if what in ('micro', 'all'):
         gen_model_fixture('micro_vit', synth.ARCHS['micro'], 7, 4, 6, True, None, ref)
+    if what in ('micro_fp_input', 'all'):
+        # VisionTransformer(input_quant=False), the reference's vit_large configuration (vit_fquant.py:925), at micro size
+        gen_model_fixture('micro_vit_fp_input', dict(synth.ARCHS['micro'], input_quant=False), 9, 4, 6, True, None, ref)
     if what in ('deit_tiny_fp', 'all'):
         # BASELINE config 1 plumbing case: float forward only
         arch = synth.ARCHS['deit_tiny']

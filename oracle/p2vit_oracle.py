@@ -443,7 +443,8 @@ class OracleViT:
         W, a = self.W, self.a
         D, H = a['embed_dim'], a['num_heads']
         self.calib, self.global_distance = {}, []
-        self._calib_act('qact_input', x)
+        if self.a.get('input_quant', True):        # VisionTransformer(input_quant=False) has no input QAct (vit_fquant.py:524,705)
+            self._calib_act('qact_input', x)
         w, b = W['patch_embed.proj.weight'], W['patch_embed.proj.bias']
         ob = _MinMax('conv_weight')
         dic = {}
@@ -513,9 +514,11 @@ class OracleViT:
             return torch.clamp(torch.round(v / s), -128, 127)
 
         # qact_input -> PatchEmbed (QConv2d k=stride=patch) -> qact     vit_fquant.py:705-715
-        s_in = c['qact_input']
-        q = q8(x, s_in)
-        tap('qact_input', q)
+        fp_in = not a.get('input_quant', True)     # the vit_large factory (vit_fquant.py:925): the fp32 image feeds the conv
+        s_in = torch.ones(1) if fp_in else c['qact_input']
+        q = x if fp_in else q8(x, s_in)
+        if not fp_in:
+            tap('qact_input', q)
         bit = bit_config[0]
         s_w = c['patch_embed.proj']['int%d' % bit]
         wq = weight_codes(W['patch_embed.proj.weight'], None, s_w, bit)
@@ -526,7 +529,14 @@ class OracleViT:
             y = y.flatten(2).transpose(1, 2)
         else:
             cols = F.unfold(q, kernel_size=P, stride=P).transpose(1, 2)          # [B, patches, C*P*P]
-            y = qgemm(cols.reshape(-1, cols.shape[-1]), s_in, wq, s_w.reshape(-1), W['patch_embed.proj.bias'])
+            if fp_in:
+                # canonical reading of F.conv2d(x_fp32, code_w * s_w, bias): the products x * code are exact in fp64; their fp64 sum,
+                # times the power-of-two s_w, plus the bias, rounded to fp32 ONCE (the fp32 conv of a given platform differs from this
+                # by its own accumulation order)
+                acc = cols.reshape(-1, cols.shape[-1]).double() @ wq.double().t()
+                y = (acc * s_w.double().reshape(1, -1).expand(1, wq.shape[0]) + W['patch_embed.proj.bias'].double()).float()
+            else:
+                y = qgemm(cols.reshape(-1, cols.shape[-1]), s_in, wq, s_w.reshape(-1), W['patch_embed.proj.bias'])
             y = y.reshape(Bn, -1, D)
         s_pe = c['patch_embed.qact']
         xv = q8(y, s_pe) * s_pe
@@ -648,10 +658,12 @@ def extract_calib(model):
     def dic(l):
         return {k: v.detach().clone().float() for k, v in l.quantizer.dic_scale.items()}
 
-    c = {'qact_input': sc(model.qact_input), 'patch_embed.proj': dic(model.patch_embed.proj),
+    c = {'patch_embed.proj': dic(model.patch_embed.proj),
          'patch_embed.qact': sc(model.patch_embed.qact), 'qact_embed': sc(model.qact_embed),
          'qact_pos': sc(model.qact_pos), 'qact1': sc(model.qact1), 'qact2': sc(model.qact2),
          'head': dic(model.head), 'act_out': sc(model.act_out)}
+    if getattr(model, 'input_quant', True):
+        c['qact_input'] = sc(model.qact_input)
     for i, blk in enumerate(model.blocks):
         p = 'blocks.%d.' % i
         for nm, m in ((p + 'attn', blk.attn), (p + 'mlp', blk.mlp)):

@@ -689,12 +689,10 @@ def test_other_configs_engine_vs_oracle(dva, oracle, name, bits):
     L = 4 * arch['depth'] + 2
     sd = dva.synth.vit_state_dict(arch, 21)
     if name == 'vit_large':
-        # the reference's vit_large factory has input_quant=False (fp32 image into the conv: refused by the engine, see
-        # VisionTransformer.export_calib); the ViT-L SHAPES (D 1024, depth 24, 16 heads, hidden 4096) are exercised with input_quant=True
-        with pytest.raises(NotImplementedError):
-            dva.vit_large_patch16_224(cfg=dva.Config()).export_calib()
-        m = dva.VisionTransformer(embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True, norm_layer=partial(dva.QIntLayerNorm, eps=1e-6),
-                                  input_quant=True, cfg=dva.Config())
+        # the reference's factory: input_quant=False (vit_fquant.py:925) - the fp32 image feeds the patch-embed convolution
+        m = dva.vit_large_patch16_224(cfg=dva.Config())
+        assert m.input_quant is False
+        arch = dict(arch, input_quant=False)
     else:
         m = dva.harness.str2model(name)(cfg=dva.Config())
     m.load_state_dict(sd, strict=False)
@@ -737,6 +735,29 @@ def test_other_token_counts_engine_vs_oracle(dva, oracle, img, patch, dim, depth
         dva.harness.calibrate_model(big, dva.synth.images(33, 1, 400).cuda())
         with pytest.raises(NotImplementedError):          # 626 tokens: P2V_MAX_TOKENS = 608
             big(dva.synth.images(33, 1, 400).cuda(), [8] * 6)
+
+
+def test_fp_input_model_engine_vs_reference_golden(dva, oracle, synth):
+    """input_quant=False on the engine (k_embed_fp32: fp64 accumulation of the exact products, one rounding) against the REAL reference's
+    logits and top-5 for the three bit configurations (tests/golden/micro_vit_fp_input.npz) and against the oracle."""
+    g = load_golden('micro_vit_fp_input')
+    a = synth.ARCHS['micro']
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('w/')}
+    m = dva.VisionTransformer(img_size=a['img_size'], patch_size=a['patch_size'], embed_dim=a['embed_dim'], depth=a['depth'],
+                              num_heads=a['num_heads'], num_classes=a['num_classes'], mlp_ratio=a['mlp_ratio'], qkv_bias=True,
+                              norm_layer=partial(dva.QIntLayerNorm, eps=1e-6), input_quant=False, cfg=dva.Config())
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda().eval()
+    dva.harness.calibrate_model(m, torch.from_numpy(g['x_cal']).cuda())
+    x = torch.from_numpy(g['x_ev'])
+    orc = oracle.OracleViT(dict(a, input_quant=False), sd)
+    orc.calib = m.export_calib()
+    for tag in ('q8', 'q4', 'qmix'):
+        bc = _bits(g, tag, 10)
+        out = m(x.cuda(), bc, False)[0].cpu()
+        assert np.array_equal(out.numpy(), g['logits/' + tag]), tag
+        assert np.array_equal(out.topk(5, 1, True, True)[1].numpy(), g['top5/' + tag]), tag
+        assert torch.equal(out, orc.quant_forward(x, bc)), tag
 
 
 def test_custom_ops_match_c_abi(dva, oracle, micro):

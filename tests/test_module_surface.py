@@ -73,6 +73,28 @@ def test_calibration_identical_to_reference(dva, micro):
         m(micro['x_ev'], None)
 
 
+def test_fp_input_model_calibration_identical_to_reference(dva, synth):
+    """input_quant=False (the vit_large factory's configuration) through the drop-in surface: the product's calibration reproduces
+    the real reference's scales of tests/golden/micro_vit_fp_input.npz; export_calib has no qact_input entry."""
+    from functools import partial
+    g = load_golden('micro_vit_fp_input')
+    a = synth.ARCHS['micro']
+    m = dva.VisionTransformer(img_size=a['img_size'], patch_size=a['patch_size'], embed_dim=a['embed_dim'], depth=a['depth'],
+                              num_heads=a['num_heads'], num_classes=a['num_classes'], mlp_ratio=a['mlp_ratio'], qkv_bias=True,
+                              norm_layer=partial(dva.QIntLayerNorm, eps=1e-6), input_quant=False, cfg=dva.Config(True, True, 'minmax'))
+    m.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('w/')}, strict=False)
+    m.eval()
+    with torch.no_grad():
+        assert np.array_equal(m(torch.from_numpy(g['x_ev']))[0].numpy(), g['fp_logits'])
+    out = dva.harness.calibrate_model(m, torch.from_numpy(g['x_cal']))[0]
+    assert np.abs(out.numpy() - g['calib_logits']).max() <= 1e-5
+    flat = dva.calib_io.flatten(m.export_calib())
+    assert 'qact_input' not in flat and len(flat) == sum(1 for k in g.files if k.startswith('calib/'))
+    for k, v in flat.items():
+        assert np.array_equal(v.numpy().reshape(g['calib/' + k].shape), g['calib/' + k]), k
+    assert dva.vit_large_patch16_224.__name__ == 'vit_large_patch16_224'
+
+
 def test_module_level_ops_against_kats(dva):
     g = load_golden('kat_ops')
     for e in range(3, 9):

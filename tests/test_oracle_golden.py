@@ -181,3 +181,33 @@ def test_deit_tiny_float_config1(oracle, synth):
     out = orc.float_forward(synth.images(int(g['seed']), 4, 224, offset=1000))
     assert np.abs(out.numpy() - g['fp_logits']).max() <= 1e-5
     assert orc.flops() == [int(v) for v in g['flops']]
+
+
+def test_micro_fp_input_against_reference(oracle, synth):
+    """VisionTransformer(input_quant=False) - the configuration of the reference's vit_large factory (vit_fquant.py:925): the fp32
+    image feeds the fake-quantised patch-embed convolution.  Fixture from the REAL reference at micro size (oracle/gen_golden.py
+    micro_fp_input): calibration identical, all 26 taps and the logits of the three bit configurations bit-equal with the oracle's
+    canonical reading of that convolution (fp64 sum of the exact products, one rounding)."""
+    g = load_golden('micro_vit_fp_input')
+    arch = dict(synth.ARCHS['micro'], input_quant=False)
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('w/')}
+    orc = oracle.OracleViT(arch, sd)
+    assert np.array_equal(orc.float_forward(torch.from_numpy(g['x_ev'])).numpy(), g['fp_logits'])
+    with torch.no_grad():
+        cal = orc.calibrate(torch.from_numpy(g['x_cal']))
+    assert np.abs(cal.numpy() - g['calib_logits']).max() <= 1e-5
+    flat = oracle.flatten_calib(orc.calib)
+    assert 'qact_input' not in flat and len(flat) == sum(1 for k in g.files if k.startswith('calib/'))
+    for k, v in flat.items():
+        assert np.array_equal(v.numpy().reshape(g['calib/' + k].shape), g['calib/' + k]), k
+    for tag in CFGS:
+        taps = {}
+        out = orc.quant_forward(torch.from_numpy(g['x_ev']), _bits(g, tag, 10), taps)
+        assert np.array_equal(out.numpy(), g['logits/' + tag]), tag
+        n = 0
+        for k in g.files:
+            if k.startswith('taps/%s/' % tag):
+                name = k.split('/', 2)[2]
+                assert np.array_equal(taps[name].numpy().reshape(g[k].shape).astype(np.int64), g[k].astype(np.int64)), (tag, name)
+                n += 1
+        assert tag == 'q4' or n == 26
