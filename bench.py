@@ -300,12 +300,12 @@ def main():
     # HBM-side bytes of that launch: PMC counters cannot be read inside the run (rocprofv3 wraps the process), so the figure is the
     # one tools/pmc.sh + tools/make_pmc_summary.py measured for the same launch size and committed; labelled as such, null if absent
     roof['traffic'], roof['traffic_source'] = None, None
-    pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
-    if os.path.exists(pmc) and args.model == MODEL:
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json' if args.model == MODEL else 'pmc_summary_%s.json' % args.model)
+    if os.path.exists(pmc):
         try:
             t = json.load(open(pmc))
             if int(t.get('_images_per_launch', -1)) == Bl and t.get(dom) is not None:
-                roof['traffic'], roof['traffic_source'] = t.get(dom), 'profiles/pmc_summary.json (separate rocprofv3 --pmc passes of this command, not this run)'
+                roof['traffic'], roof['traffic_source'] = t.get(dom), 'profiles/%s (separate rocprofv3 --pmc passes of this command, not this run)' % os.path.basename(pmc)
         except Exception:
             pass
     breakdown = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}

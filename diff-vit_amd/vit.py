@@ -339,7 +339,7 @@ class VisionTransformer(nn.Module):
         # replacing a submodule (e.g. swapping the head) invalidates the cached module lists and the frozen plan; the reference walks
         # self.modules() on every state switch (vit_fquant.py:667-698)
         if isinstance(value, nn.Module) and '_qmods' in self.__dict__:
-            self.__dict__['_qmods'] = self.__dict__['_lnmods'] = self.__dict__['_plan'] = None
+            self.__dict__['_qmods'] = self.__dict__['_lnmods'] = self.__dict__['_plan'] = self.__dict__['_flops'] = None
         super().__setattr__(name, value)
 
     def _q_modules(self, refresh=False):
@@ -427,16 +427,19 @@ class VisionTransformer(nn.Module):
 
     def flops(self):
         """the FLOPs list the reference appends layer by layer (MAC counts; layers_quant.py:482,329,344;
-        vit_fquant.py:304,336,794)."""
-        a = self.arch
-        D, P = a['embed_dim'], a['patch_size']
-        g = a['img_size'] // P
-        N, Hd = g * g + 1, int(D * a['mlp_ratio'])
-        out = [self.in_chans * P * P * D * g * g]
-        for _ in range(self.depth):
-            out += [N * D * 3 * D, N * D * D, N * D * Hd, N * Hd * D]
-        out.append(D * self.num_classes)
-        return out
+        vit_fquant.py:304,336,794).  A function of the architecture only: computed once, a fresh list per call (callers may mutate it)."""
+        cached = self.__dict__.get('_flops')
+        if cached is None:
+            a = self.arch
+            D, P = a['embed_dim'], a['patch_size']
+            g = a['img_size'] // P
+            N, Hd = g * g + 1, int(D * a['mlp_ratio'])
+            cached = [self.in_chans * P * P * D * g * g]
+            for _ in range(self.depth):
+                cached += [N * D * 3 * D, N * D * D, N * D * Hd, N * Hd * D]
+            cached.append(D * self.num_classes)
+            self.__dict__['_flops'] = cached
+        return list(cached)
 
     # ---- forward -----------------------------------------------------------------------------------------------
     def forward_features(self, x, FLOPs, global_distance, bit_config, global_plot, hessian_statistic=False):
