@@ -2294,7 +2294,8 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   if (epi != P2V_EPI_HEAD && epi != P2V_EPI_EMBED) {
     // 256-row tiles (8 waves, two workgroups per CU) when the grid still gives every CU its two workgroups; else 128-row tiles
     const long long tiles256 = (long long)((g.M + 255) / 256) * g.tiles_n;
-    const bool big = g_gemm_stages == 3 && (g_gemm_tile == 256 || (g_gemm_tile == 0 && tiles256 >= 2LL * device_cus()));
+    // (packed int4 weights keep 128 rows: the 8-wave form moves a 4 KB W tile as eight half-wave pieces and measured 3 % slower on DeiT-B W4)
+    const bool big = g_gemm_stages == 3 && (g_gemm_tile == 256 || (g_gemm_tile == 0 && !g.w4 && tiles256 >= 2LL * device_cus()));
     const int tiles_m = big ? (g.M + 255) / 256 : (g.M + GBM - 1) / GBM;
     dim3 grid4(g.tiles_n * tiles_m), block4(big ? 512 : 256);
     unsigned tab_bytes = (epi == P2V_EPI_GELU && g.ep.gelu.table) ? (unsigned)g.ep.gelu.cells * 8u : 0u;
