@@ -501,10 +501,17 @@ __device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_
     if (EPI == P2V_EPI_GELU_TAB) {
 #ifdef P2V_EXP_DUMMY   /* experiment only (never in the product build): P2V_EXP_DUMMY independent VALU instructions per 8 outputs */
       {
+#ifdef P2V_EXP_DUMMY_PK   /* the same number of instructions, packed: twice the lane operations */
+        v2f dp_ = {yy[0][0], yy[0][0]};
+#pragma unroll
+        for (int q_ = 0; q_ < P2V_EXP_DUMMY; ++q_) asm volatile("v_pk_add_f32 %0, %1, %1" : "=v"(dp_) : "v"((v2f){yy[0][q_ & 3], yy[1][q_ & 3]}));
+        asm volatile("" :: "v"(dp_));
+#else
         float dm_ = yy[0][0];
 #pragma unroll
         for (int q_ = 0; q_ < P2V_EXP_DUMMY; ++q_) asm volatile("v_add_f32 %0, 1.0, %1" : "=v"(dm_) : "v"(yy[0][q_ & 3]));
         asm volatile("" :: "v"(dm_));
+#endif
       }
 #endif
       gelu_tab_q8x8(yy[0], yy[1], gtab, g.ep.gelu.k, g.ep.gelu.off, (float)(g.ep.gelu.cells - 1), d[0][gq], d[1][gq]);
