@@ -980,6 +980,7 @@ struct LnLane {
   float4 gm[NCH], bt[NCH], pm[NCH];   // gamma*io, beta*io, post_mul
   int4 mki[NCH];                      // PTF mask (in_scale / s1)
   float gmin, gmax;                   // extreme |gamma*io| over all channels
+  float bmax;                         // max |beta*io| over all channels (bound of the LayerNorm offset, see ln_row)
   bool pot;                           // 1/out_scale is a power of two for every channel and the fold is exact
   bool pm_one;                        // post_mul == 1 for every channel (norm1 of P2-ViT: out_scale / channel_scale / qact0 scale): no second requant
 };
@@ -1027,7 +1028,7 @@ __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_g
   L.pm_one = false;
 #endif
   // extreme |g io| over all channels (every row group covers all of them)
-  float gmin = 3.0e38f, gmax = 0.f;
+  float gmin = 3.0e38f, gmax = 0.f, bmax = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = (l32 + LANES * i) * 4;
@@ -1035,6 +1036,7 @@ __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_g
     const float4 gv = *reinterpret_cast<const float4*>(sG + c);
     L.gm[i] = gv;
     L.bt[i] = *reinterpret_cast<const float4*>(sB + c);
+    if (L.on[i]) bmax = fmaxf(bmax, fmaxf(fmaxf(fabsf(L.bt[i].x), fabsf(L.bt[i].y)), fmaxf(fabsf(L.bt[i].z), fabsf(L.bt[i].w))));
     L.pm[i] = *reinterpret_cast<const float4*>(sP + c);
     L.mki[i] = *reinterpret_cast<const int4*>(sM + c);
     const float lo = fminf(fminf(fabsf(gv.x), fabsf(gv.y)), fminf(fabsf(gv.z), fabsf(gv.w)));
@@ -1043,18 +1045,22 @@ __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_g
     gmax = fmaxf(gmax, L.on[i] ? hi : 0.f);
   }
   {   // positive floats order like their bit patterns: integer min/max butterflies inside the half wave
-    int lo = (int)__float_as_uint(gmin), hi = (int)__float_as_uint(gmax);
-#define LN_MM(ctrl) lo = min(lo, __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false)); hi = max(hi, __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false));
+    int lo = (int)__float_as_uint(gmin), hi = (int)__float_as_uint(gmax), bh = (int)__float_as_uint(bmax);
+#define LN_MM(ctrl) lo = min(lo, __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false)); hi = max(hi, __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false)); \
+                    bh = max(bh, __builtin_amdgcn_update_dpp(bh, bh, ctrl, 0xF, 0xF, false));
     LN_MM(0xB1) LN_MM(0x4E) LN_MM(0x141) LN_MM(0x140)
 #undef LN_MM
     lo = min(lo, __builtin_amdgcn_ds_swizzle(lo, 0x401F));
     hi = max(hi, __builtin_amdgcn_ds_swizzle(hi, 0x401F));
+    bh = max(bh, __builtin_amdgcn_ds_swizzle(bh, 0x401F));
     if (LANES == 64) {
       lo = min(lo, __shfl_xor(lo, 32));
       hi = max(hi, __shfl_xor(hi, 32));
+      bh = max(bh, __shfl_xor(bh, 32));
     }
     L.gmin = __uint_as_float((unsigned)lo);
     L.gmax = __uint_as_float((unsigned)hi);
+    L.bmax = __uint_as_float((unsigned)bh);
   }
 }
 
@@ -1092,7 +1098,12 @@ __device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane
   const float rs = s1 / stdv;
   const float mos = mean / stdv;
   // |A| = RN(rs*|g io|) is monotone in |g io|: the two extreme channels bound every channel exactly
-  const bool fast = L.pot && rs * L.gmin >= 0x1p-24f && rs * L.gmax < 256.f;
+  // ... and the offset Bv = rint(t * 2^N) (t = beta*io - mos*gamma*io) is rounded by adding and subtracting 1.5 * 2^(23-N), which is
+  // rint on the 2^-N grid (ties to even included) as long as |t| * 2^N < 2^22: |t| <= bmax + |mos| gmax and N <= 134 - exp(rs * gmin),
+  // so one comparison per row against 2^(exp(rs*gmin) - 112) bounds every channel (1 % margin for the roundings of t itself)
+  const float amin = rs * L.gmin;
+  const float tlim = __uint_as_float((((__float_as_uint(amin) >> 23) & 255u) + 15u) << 23);       // 2^22 * 2^-(134 - e_min)
+  const bool fast = L.pot && amin >= 0x1p-24f && rs * L.gmax < 256.f && (L.bmax + fabsf(mos) * L.gmax) * 1.01f < tlim;
   if (fast) {
     auto chain = [&](auto PM1c) {
       constexpr bool PM1 = decltype(PM1c)::value;
@@ -1111,8 +1122,15 @@ __device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane
             const float t = b4[j + e] - mos * g4[j + e];
             const unsigned Ab = __float_as_uint(A);
             T2[e] = __uint_as_float(Ab & 0xFFFF0000u);                              // sign * M * 2^-N
+#ifdef P2V_EXP_NOTRIM
             const int N = 134 - (int)((Ab >> 23) & 255u);                           // in [0, 31] by the range test
             Bq2[e] = ldexpf(rintf(ldexpf(t, N)), -N);                               // Bv * 2^-N
+#else
+            // Bv * 2^-N = t rounded to the 2^-N grid, N = 134 - exp(A): C = 1.5 * 2^(23-N) has the exponent field exp(A) + 16 (4 full-rate
+            // instructions instead of bfe, add, sub, ldexp, rndne, ldexp: tools/ubench/op_cost.hip, profiles/r03_op_cost.txt)
+            const float Cm = __uint_as_float((Ab & 0x7F800000u) + 0x08400000u);
+            Bq2[e] = (t + Cm) - Cm;
+#endif
           }
           const v2f x2 = {xq[i][j], xq[i][j + 1]};
           const v2f o2 = __builtin_elementwise_fma(T2, x2, Bq2);
