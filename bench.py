@@ -18,6 +18,11 @@ import sys
 import time
 
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL across processes needs it on this driver
+# One hardware queue per HIP stream: the runtime's default of 4 is exhausted as soon as RCCL is initialised (its streams take queues of
+# their own), two of the three slice streams then share one and the step falls from 2.64 to 3.6 ms (70 k img/s) on EVERY rank of a
+# multi-GPU run - measured with a one-rank RCCL group, tools/gather_cost.py; 8 queues: 2.64 ms with the all-gather in the step.
+# Read by the HIP runtime when it initialises, i.e. before the first HIP call of the process (diff_vit_amd sets the same default).
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch  # noqa: E402
 
@@ -130,7 +135,7 @@ def spawn_ranks(n):
         port = sk.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    r = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    r = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GPU_MAX_HW_QUEUES=os.environ.get('GPU_MAX_HW_QUEUES', '8')))
     sys.exit(r.returncode)
 
 

@@ -1,6 +1,14 @@
 """p2vit-mi355x: MI355X-native PoT-PTQ quantized ViT forward -- a drop-in for the quantized inference path of
 LeSN-Lab/diff-ViT (models/ptq + models/vit_fquant + config).  ``from diff_vit_amd import *`` yields what the
 reference's ``from models import *`` + ``from config import Config`` yield for this path.  See DESIGN.md."""
+import os as _os
+
+# One hardware queue per HIP stream: the slices of FrozenPlan.forward_streams run on three streams, and the runtime's default of four
+# hardware queues is used up as soon as RCCL (torch.distributed "nccl") is initialised in the process - two slice streams then share a
+# queue and every rank's step takes 3.6 instead of 2.64 ms (tools/gather_cost.py).  The HIP runtime reads the variable when it initialises
+# (the first HIP call of the process); an explicit setting of the user wins.
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 from . import synth, engine, calib_io, checkpoint, dp, harness, search, ops  # noqa: F401
 from .config import Config  # noqa: F401
 from .plan import FrozenPlan  # noqa: F401

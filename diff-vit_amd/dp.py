@@ -5,6 +5,11 @@ cross-sample statistic.  One process per GPU (``torch.distributed``, backend "nc
 the CPU tests), the frozen plan is replicated, the global batch is split contiguously, and the only exchange step is one
 all-gather of the logits per batch: fp32 [B_local, classes] (1 MB per GPU at 256 x 1000) or, with
 ``codes=True``, the int8 logit codes (4x smaller; logits are codes * act_out scale).
+
+The collective itself costs ~10 us per step (tools/gather_cost.py: 2.636 -> 2.643 ms with a one-rank RCCL group).  What does cost is
+INITIALISING RCCL with the runtime's default of four hardware queues: its streams take queues, two of the three slice streams of the
+forward then share one, and the step takes 3.6 ms on every rank.  ``import diff_vit_amd`` therefore defaults ``GPU_MAX_HW_QUEUES`` to 8
+(it must be in the environment before the process makes its first HIP call).
 """
 import torch
 import torch.distributed as dist
