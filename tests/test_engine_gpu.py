@@ -1190,3 +1190,37 @@ def test_ln_gemm_packed_int4_fragments(dva, oracle, C_, N, M, kind):
     finally:
         E.check(L.p2v_set_tuning(b'ln_gemm_version', 2))
     assert len(torch.unique(out_sep)) > 20
+
+
+@pytest.mark.parametrize('tile', [128, 256])
+def test_gemm_gelu_table_beyond_64kb_of_lds(dva, oracle, tile):
+    """1/scale = 256: the GELU threshold table has 2111 cells (16.5 KB) and, on top of the ring of the tiled GEMM, passes the 64 KB of LDS a
+    kernel gets by default - the launcher asks for the larger dynamic block.  Codes equal the arithmetic epilogue's and the oracle's."""
+    E, S = dva.engine, dva.synth
+    L = E.lib()
+    M, K, N = 300, 128, 256
+    x = _rand_codes(S, 23, 'gx', (M, K)); w = _rand_codes(S, 23, 'gw', (N, K), 30.0)
+    bias = S.normal(23, 'gb', (N,), 0.2)
+    s_x, s_w, inv_s = 2.0 ** -8, 2.0 ** -9, 256.0
+    tab = E.gelu_table(inv_s, 'cuda')
+    assert tab.cells * 8 > 15 * 1024
+    xd, wd = x.to(torch.int8).cuda(), w.to(torch.int8).cuda()
+    cs = torch.full((N,), s_x * s_w).cuda(); bd = bias.cuda()
+    lin = E.Linear(E.ptr(wd), E.ptr(cs), E.ptr(bd), None, 0)
+    outs = []
+    try:
+        E.check(L.p2v_set_tuning(b'gemm_tile', tile))
+        for use_tab in (True, False):
+            epi = E.Epilogue(); epi.inv_s_out = inv_s
+            if use_tab:
+                epi.gelu = tab
+            out = torch.full((M, N), 91, dtype=torch.int8, device='cuda')
+            E.check(L.p2v_gemm_i8(E.EPI_GELU, E.ptr(xd), K, M, K, N, C.byref(lin), C.byref(epi), E.ptr(out), N, None, E.stream_ptr()))
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+    finally:
+        E.check(L.p2v_set_tuning(b'gemm_tile', 0))
+    assert torch.equal(outs[0], outs[1])
+    y = oracle.qgemm(x, torch.tensor(s_x), w, torch.full((N,), s_w), bias)
+    ref = torch.clamp(torch.round(oracle.gelu_rn(y) * inv_s), -128, 127)
+    assert torch.equal(outs[0].float(), ref) and len(torch.unique(outs[0])) > 50
