@@ -17,7 +17,7 @@ with torch.no_grad():
     prof = plan.profile(xb); prof = plan.profile(xb)
 epi = {0: 'requant', 1: 'gelu', 2: 'resid', 4: 'head'}
 agg = collections.OrderedDict()
-r = plan._recorded[(B, 0)]
+r = plan._recorded[(B, 0, True)] if (B, 0, True) in plan._recorded else plan._recorded[(B, 0)]
 for i, (kind, e, ms) in enumerate(prof):
     o = r['ops'][i]
     key = kind + ('/' + epi.get(e, str(e)) + ' K=%d N=%d' % (o.K, o.N) if kind == 'gemm' else (' C=%d' % o.N if kind == 'layernorm' else (' T=%d H=%d' % (o.i1, o.i2) if kind == 'window_attention' else '')))
