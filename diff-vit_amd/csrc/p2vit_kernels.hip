@@ -499,6 +499,29 @@ __device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_
       }
     }
     if (EPI == P2V_EPI_GELU_TAB) {
+#ifdef P2V_EXP_DUMMY_MFMA   /* experiment only: P2V_EXP_DUMMY_MFMA extra v_mfma_i32_32x32x32_i8 on live (random) data per 8 outputs */
+      {
+        v16i dacc_ = acc[0];
+        const v4i da_ = {__float_as_int(yy[0][0]), __float_as_int(yy[0][1]), __float_as_int(yy[0][2]), __float_as_int(yy[0][3])};
+        const v4i db_ = {__float_as_int(yy[1][0]), __float_as_int(yy[1][1]), __float_as_int(yy[1][2]), __float_as_int(yy[1][3])};
+#pragma unroll
+        for (int q_ = 0; q_ < P2V_EXP_DUMMY_MFMA; ++q_) dacc_ = __builtin_amdgcn_mfma_i32_32x32x32_i8(da_, db_, dacc_, 0, 0, 0);
+        asm volatile("" :: "v"(dacc_));
+      }
+#endif
+#ifdef P2V_EXP_DUMMY_LDS    /* experiment only: P2V_EXP_DUMMY_LDS extra ds_read_b128 (conflict-free, consecutive lanes) per 8 outputs */
+      {
+        v4i dl_ = {0, 0, 0, 0};
+#pragma unroll
+        for (int q_ = 0; q_ < P2V_EXP_DUMMY_LDS; ++q_) {
+          v4i t_;
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t_) : "v"((unsigned)((threadIdx.x & 63) * 16)), "i"(q_ * 1024));
+          dl_ ^= t_;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" :: "v"(dl_));
+      }
+#endif
 #ifdef P2V_EXP_DUMMY   /* experiment only (never in the product build): P2V_EXP_DUMMY independent VALU instructions per 8 outputs */
       {
 #ifdef P2V_EXP_DUMMY_PK   /* the same number of instructions, packed: twice the lane operations */
