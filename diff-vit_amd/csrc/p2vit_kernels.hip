@@ -50,6 +50,28 @@ __device__ __forceinline__ unsigned pack4_sat(float r0, float r1, float r2, floa
   return w ^ 0x80808080u;
 }
 __device__ __forceinline__ float sat8f(float v) { return clamp8f(rintf(v)); }
+// clamp(rint(o), -128, 127) of four fp32 values as four int8 bytes WITHOUT v_rndne / v_cvt_pk: the clamp commutes with the rounding (its
+// bounds are integers, rint is monotone), and adding 1.5 * 2^23 rounds the clamped value to an integer (round-half-even: the addition's own
+// rounding on the unit grid) whose two's-complement code is the low byte of the sum; the SDWA form writes that byte into its place of the
+// packed dword.  v_med3 + v_add_f32_sdwa = 10.4 cycles per value against 14.4 for rndne, +128, cvt_pk_u8 (profiles/r03_op_cost.txt).
+// Finite inputs only (a NaN would not give the -128 that v_cvt_pk_u8_f32 does).
+#if defined(P2V_EXP_NOTRIM2) || defined(P2V_EXP_OLDPACK)   /* A/B baseline builds only (tools/exp) */
+__device__ __forceinline__ float pre_pack(float o) { return rintf(o); }
+__device__ __forceinline__ unsigned pack4_pre(float r0, float r1, float r2, float r3) { return pack4_sat(r0, r1, r2, r3); }
+#else
+__device__ __forceinline__ float pre_pack(float o) { return clamp8f(o); }
+__device__ __forceinline__ unsigned pack4_pre(float c0, float c1, float c2, float c3) {       // c = pre_pack(o)
+  const float magic = 12582912.f;
+  unsigned w = __float_as_uint(c0 + magic);                           // byte 0; bytes 1-3 are overwritten below
+  asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(c1), "v"(magic));
+  asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(c2), "v"(magic));
+  asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(w) : "v"(c3), "v"(magic));
+  return w;
+}
+#endif
+__device__ __forceinline__ unsigned pack4_rne_sat(float o0, float o1, float o2, float o3) {
+  return pack4_pre(pre_pack(o0), pre_pack(o1), pre_pack(o2), pre_pack(o3));
+}
 
 // Exchange between the two 32-lane halves so that each lane ends with 16 CONTIGUOUS bytes of an MFMA
 // 32x32 accumulator column block.  In: d[g] = bytes [8g+4h, 8g+4h+4) (h = lane>>5).
@@ -311,7 +333,7 @@ __global__ __launch_bounds__(256) void k_quantize_patchify(const float* __restri
       unsigned v = 0;
       if (live) {
         const float4 f = *reinterpret_cast<const float4*>(img + (long long)b * C * H * W + chan_off + (long long)py * P * W + px * P);
-        v = pack4_sat(rintf(f.x * inv_s), rintf(f.y * inv_s), rintf(f.z * inv_s), rintf(f.w * inv_s));
+        v = pack4_rne_sat(f.x * inv_s, f.y * inv_s, f.z * inv_s, f.w * inv_s);
       }
       *reinterpret_cast<unsigned*>(out + row * k_pad + col) = v;
     }
@@ -545,8 +567,8 @@ __device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_
       const float (&y)[4] = yy[b];
       float q[4];
       if (EPI == P2V_EPI_REQUANT) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = rintf(y[i]);
+        d[b][gq] = pack4_rne_sat(y[0], y[1], y[2], y[3]);
+        continue;
       } else if (EPI == P2V_EPI_GELU) {
         gelu_q8x4(y, g.ep.inv_s_out, q);
       } else {   // RESID, see gemm_epilogue_tile
@@ -1001,7 +1023,7 @@ template <int NCH>
 struct LnLane {
   bool on[NCH];
   float4 gm[NCH], bt[NCH], pm[NCH];   // gamma*io, beta*io, post_mul
-  int4 mki[NCH];                      // PTF mask (in_scale / s1)
+  float4 mkf[NCH];                    // PTF mask (in_scale / s1): 1, 2, 4 or 8
   float gmin, gmax;                   // extreme |gamma*io| over all channels
   float bmax;                         // max |beta*io| over all channels (bound of the LayerNorm offset, see ln_row)
   bool pot;                           // 1/out_scale is a power of two for every channel and the fold is exact
@@ -1043,7 +1065,7 @@ __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_g
     *reinterpret_cast<float4*>(sG + c) = make_float4(go[0], go[1], go[2], go[3]);
     *reinterpret_cast<float4*>(sB + c) = make_float4(bo[0], bo[1], bo[2], bo[3]);
     *reinterpret_cast<float4*>(sP + c) = pmv;
-    *reinterpret_cast<int4*>(sM + c) = make_int4((int)mk.x, (int)mk.y, (int)mk.z, (int)mk.w);
+    *reinterpret_cast<float4*>(sM + c) = mk;
   }
   L.pot = __syncthreads_and(potf) != 0;
   L.pm_one = __syncthreads_and(pm1) != 0;
@@ -1061,7 +1083,7 @@ __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_g
     L.bt[i] = *reinterpret_cast<const float4*>(sB + c);
     if (L.on[i]) bmax = fmaxf(bmax, fmaxf(fmaxf(fabsf(L.bt[i].x), fabsf(L.bt[i].y)), fmaxf(fabsf(L.bt[i].z), fabsf(L.bt[i].w))));
     L.pm[i] = *reinterpret_cast<const float4*>(sP + c);
-    L.mki[i] = *reinterpret_cast<const int4*>(sM + c);
+    L.mkf[i] = *reinterpret_cast<const float4*>(sM + c);
     const float lo = fminf(fminf(fabsf(gv.x), fabsf(gv.y)), fminf(fabsf(gv.z), fabsf(gv.w)));
     const float hi = fmaxf(fmaxf(fabsf(gv.x), fabsf(gv.y)), fmaxf(fabsf(gv.z), fabsf(gv.w)));
     gmin = fminf(gmin, L.on[i] ? lo : 3.0e38f);
@@ -1095,12 +1117,14 @@ __device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane
   const float Cf = (float)C;
   const float s1oC = s1 / Cf;
   float xq[NCH][4];
-  int S1 = 0;
+  int S1;
   unsigned S2 = 0;                              // C * (128*8)^2 <= 2^31 for C <= 2048: exact in 32 unsigned bits
+#if defined(P2V_EXP_NOTRIM2) || defined(P2V_EXP_OLDSUMS)
+  S1 = 0;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const unsigned w = wcur[i];
-    const int m4[4] = {L.mki[i].x, L.mki[i].y, L.mki[i].z, L.mki[i].w};
+    const int m4[4] = {(int)L.mkf[i].x, (int)L.mkf[i].y, (int)L.mkf[i].z, (int)L.mkf[i].w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int v = __mul24(sx8(w, j), m4[j]);           // x_q * in_scale_mask  (layers.py:269-273); w == 0 past C
@@ -1109,6 +1133,25 @@ __device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane
       S2 += (unsigned)__mul24(v, v);
     }
   }
+#else
+  // the lane's partial sums in fp32: |x_q| <= 1024, so sum x_q of 32 values and sum x_q^2 of 16 values (<= 2^24) are exact - full-rate
+  // add / fma instead of 24-bit multiplies and three-operand adds (profiles/r03_op_cost.txt); the cross-lane sums stay integers
+  float S1p = 0.f, S2p = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const unsigned w = wcur[i];
+    const float m4[4] = {L.mkf[i].x, L.mkf[i].y, L.mkf[i].z, L.mkf[i].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xq[i][j] = (float)sx8(w, j) * m4[j];       // x_q * in_scale_mask  (layers.py:269-273), exact; w == 0 past C
+    S1p += (xq[i][0] + xq[i][1]) + (xq[i][2] + xq[i][3]);                  // (short dependency chains: a wave may be alone on its SIMD)
+    S2p += __builtin_fmaf(xq[i][1], xq[i][1], xq[i][0] * xq[i][0]) + __builtin_fmaf(xq[i][3], xq[i][3], xq[i][2] * xq[i][2]);
+    if ((i & 3) == 3 || i == NCH - 1) {
+      S2 += (unsigned)S2p;
+      S2p = 0.f;
+    }
+  }
+  S1 = (int)S1p;
+#endif
   S1 = half_wave_sum(S1);
   S2 = (unsigned)half_wave_sum((int)S2);        // two's-complement adds: the unsigned total is exact
   if (LANES == 64) {
@@ -1158,14 +1201,14 @@ __device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane
           const v2f x2 = {xq[i][j], xq[i][j + 1]};
           const v2f o2 = __builtin_elementwise_fma(T2, x2, Bq2);
           if (PM1) {                                                                // out * 1: the LayerNorm output IS the code
-            q[j] = rintf(o2[0]);
-            q[j + 1] = rintf(o2[1]);
+            q[j] = o2[0];
+            q[j + 1] = o2[1];
           } else {
-            q[j] = rintf(rintf(o2[0]) * p4[j]);
-            q[j + 1] = rintf(rintf(o2[1]) * p4[j + 1]);
+            q[j] = rintf(o2[0]) * p4[j];
+            q[j + 1] = rintf(o2[1]) * p4[j + 1];
           }
         }
-        outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
+        outw[i] = pack4_rne_sat(q[0], q[1], q[2], q[3]);                            // the (last) rounding is the packing's
       }
     };
     if (L.pm_one) chain(std::integral_constant<bool, true>{});      // wave-uniform
@@ -1680,17 +1723,17 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
         float r0[4], r1[4];
         LG2_MFMA(6 * gq + 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r0[i] = rintf(y0[i]);
+        for (int i = 0; i < 4; ++i) r0[i] = pre_pack(y0[i]);
         LG2_FENCE();
         LG2_MFMA(6 * gq + 3);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r1[i] = rintf(y1[i]);
+        for (int i = 0; i < 4; ++i) r1[i] = pre_pack(y1[i]);
         LG2_FENCE();
         LG2_MFMA(6 * gq + 4);
-        d[0][gq] = pack4_sat(r0[0], r0[1], r0[2], r0[3]);
+        d[0][gq] = pack4_pre(r0[0], r0[1], r0[2], r0[3]);
         LG2_FENCE();
         LG2_MFMA(6 * gq + 5);
-        d[1][gq] = pack4_sat(r1[0], r1[1], r1[2], r1[3]);
+        d[1][gq] = pack4_pre(r1[0], r1[1], r1[2], r1[3]);
         LG2_FENCE();
       }
     };
@@ -2018,7 +2061,7 @@ __global__ __launch_bounds__(512, NKP <= 7 ? 4 : (NKP <= 10 ? 3 : 2)) void k_lis
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt)
         *reinterpret_cast<unsigned*>(dst + dt * 16) =
-            pack4_sat(rintf(o[dt][0] * a.at.av_mul), rintf(o[dt][1] * a.at.av_mul), rintf(o[dt][2] * a.at.av_mul), rintf(o[dt][3] * a.at.av_mul));
+            pack4_rne_sat(o[dt][0] * a.at.av_mul, o[dt][1] * a.at.av_mul, o[dt][2] * a.at.av_mul, o[dt][3] * a.at.av_mul);
     }
     AT_STAMP(stamp_base + 3);
     stamp_base += 4;
@@ -2227,7 +2270,7 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
         *reinterpret_cast<unsigned*>(dst + dt * 16) =
-            pack4_sat(rintf(o[dt][0] * av_mul), rintf(o[dt][1] * av_mul), rintf(o[dt][2] * av_mul), rintf(o[dt][3] * av_mul));
+            pack4_rne_sat(o[dt][0] * av_mul, o[dt][1] * av_mul, o[dt][2] * av_mul, o[dt][3] * av_mul);
     }
   }
 }
