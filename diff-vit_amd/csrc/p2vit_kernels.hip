@@ -2088,12 +2088,14 @@ __global__ __launch_bounds__(512, NKP <= 7 ? 4 : (NKP <= 10 ? 3 : 2)) void k_lis
 // NT = ws*ws when known at compile time (49 for the 7x7 windows of every Swin variant), 0 = generic.  A score slot (kb, r) holds
 // key kb*16 + 4g + r: when kb*16 + r >= NT it is padding in every lane and its arithmetic is dropped (3 of 16 slots at NT = 49).
 #define WA_DEAD(kb, r) (NT > 0 && (kb) * 16 + (r) >= NT)
-template <int NT>
-__global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
+// ... and when kb*16 + 12 + r < NT it is a real key in every lane: no padding test
+#define WA_PAD(kb, r) (!(NT > 0 && (kb) * 16 + 12 + (r) < NT))
+template <int NT, bool TAP>
+__global__ __launch_bounds__(256, 3) void k_window_attention(WinAttnArgs a) {
   constexpr int VSTRIDE = WA_KEYS + 4;                                         // bf16 elements
   __shared__ __attribute__((aligned(16))) int8_t sK[4][WA_KEYS * WA_HD];
   __shared__ __attribute__((aligned(16))) unsigned short sVt[4][WA_HD * VSTRIDE];
-  __shared__ int8_t sT[4][232];                                               // bias-table column of the head ((2*8-1)^2 = 225 max)
+  __shared__ float sT[4][232];                                                // bias-table column of the head ((2*8-1)^2 = 225 max), times s_table / s_q2
   __shared__ unsigned short sMeta[WA_KEYS + 16];                               // per token: lin (y*(2ws-1)+x) | region << 10
   __shared__ long long lutE[258];
   __shared__ double lutFR[258];                                                // fp64 reciprocal of float(exp_int)
@@ -2128,7 +2130,11 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
   __syncthreads();
   if (head >= a.H) return;
   const int tsz = (2 * ws - 1) * (2 * ws - 1);
-  for (int t = lane; t < tsz; t += 64) sT[wave][t] = a.wa.table_codes[t * a.H + head];
+  const float inv_sa = 1.0f / a.wa.s_attn, inv_s2 = 1.0f / a.wa.s_q2;          // powers of two: exact
+  // qact2((a1 * s_attn + code * s_table)) = clamp(rint(fma(a1, s_attn / s_q2, code * s_table / s_q2))): the products are exact (powers of
+  // two) and the one rounding of the sum is the reference's, so the bias column is staged already scaled
+  const float tb_mul = a.wa.s_table * inv_s2, a1_mul = a.wa.s_attn * inv_s2;
+  for (int t = lane; t < tsz; t += 64) sT[wave][t] = (float)a.wa.table_codes[t * a.H + head] * tb_mul;
   // stage K rows (int8) and V^T (bf16) of the window's tokens; rows >= N are zero
   {
     const bool live = lane < N;
@@ -2152,31 +2158,52 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
   }
   const float sigma = a.wa.s_q1 * a.wa.qk_scale;                               // exact (s_q1 = 2^e)
   const float inv_u = __uint_as_float((unsigned)(254 - (int)(__float_as_uint(sigma) >> 23) + 23) << 23);   // 1 / ulp(sigma)
-  const double sig_d = (double)sigma * (double)a.wa.s_q1;                      // * s_q1 of the keys: exact scaling
-  const double u_d = (1.0 / (double)inv_u) * (double)a.wa.s_q1;
-  const float inv_sa = 1.0f / a.wa.s_attn, inv_s2 = 1.0f / a.wa.s_q2;          // powers of two: exact
-  const int m100 = (int)(100.0f * inv_s2);                                     // 100 / sf as an integer
+  // score = u * X,  X = (sigma / u) * S1 + S2 an integer below 2^53 (u = ulp(sigma) * s_q1 of the keys, a power of two): RN32(u * X) = u * RN32(X)
+  const float sig_m = sigma * inv_u;                                           // the 24-bit significand of sigma as an integer
+  const double sig_int = (double)sig_m;
+  const float x_mul = ((1.0f / inv_u) * a.wa.s_q1) * inv_sa;                   // u / s_attn: a power of two
+  const float m100 = (float)(int)(100.0f * inv_s2);                            // 100 / sf as an integer
   const float av_mul = a.wa.s_q1 / a.wa.s_q3;
   const int c0 = (ws - 1) * (2 * ws - 1) + (ws - 1);
   const int nqb = (N + 15) >> 4;
+  // per score slot of this lane: relative-position term and region of its key (the same for every query block)
+  int linj[4][4];
+  unsigned regj[4][4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned mj = sMeta[kb * 16 + 4 * g + r];
+      linj[kb][r] = (int)(mj & 1023u);
+      regj[kb][r] = mj >> 10;
+    }
   for (int qb = 0; qb < nqb; ++qb) {
     const int qi = qb * 16 + l15;
     const int qr = qi < N ? qi : N - 1;
     const int rowq = a.wa.win_index[w * N + qr];
     const v4i qc = *reinterpret_cast<const v4i*>(a.qkv + ((long long)b * a.T + rowq) * ldq + head * WA_HD + (g & 1) * 16);
-    v4i qeta;
+    // eta plane: the lanes of g >= 2 need it, and the lane 32 below holds the same sixteen codes - each computes eight (g < 2: dwords 0-1,
+    // g >= 2: dwords 2-3) and the lower half hands its two dwords up (v_permlane32_swap).  In units of u: eta = RN32(code * m) - code * m
+    // with m = sigma / u, the significand of sigma as an integer (scaling by a power of two commutes with the rounding); the integral
+    // float goes into its byte by the magic addition of pack4_pre
+    unsigned eh[2];
+    {
+      const unsigned qh[2] = {(unsigned)(g < 2 ? qc[0] : qc[2]), (unsigned)(g < 2 ? qc[1] : qc[3])};
 #pragma unroll
-    for (int d4 = 0; d4 < 4; ++d4) {
-      unsigned pk = 0;
+      for (int d = 0; d < 2; ++d) {
+        float et[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float cf = (float)sx8((unsigned)qc[d4], e);
-        const float v = cf * sigma;                                             // RN32(code * sigma)
-        const int eta = (int)(__builtin_fmaf(cf, sigma, -v) * -inv_u);          // (v - code*sigma) / u, an integer in [-64, 64]
-        pk |= ((unsigned)eta & 255u) << (8 * e);
+        for (int e = 0; e < 4; ++e) {
+          const float cf = (float)sx8(qh[d], e);
+          const float v = cf * sig_m;                                           // RN32(code * m)
+          et[e] = __builtin_fmaf(-cf, sig_m, v);                                // exact, an integer in [-64, 64]
+        }
+        eh[d] = pack4_pre(et[0], et[1], et[2], et[3]);
       }
-      qeta[d4] = (int)pk;
     }
+    const auto up0 = __builtin_amdgcn_permlane32_swap(0u, eh[0], false, false);   // [0]: upper half := eh of the lower half
+    const auto up1 = __builtin_amdgcn_permlane32_swap(0u, eh[1], false, false);
+    const v4i qeta = {(int)up0[0], (int)up1[0], (int)eh[0], (int)eh[1]};
     const v4i fq1 = g < 2 ? qc : (v4i){0, 0, 0, 0};
     const v4i fq2 = g < 2 ? (v4i){0, 0, 0, 0} : qeta;
     v4i s1[4], s2[4];
@@ -2187,42 +2214,40 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
       s2[kb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fk, fq2, (v4i){0, 0, 0, 0}, 0, 0, 0);
     }
     const unsigned mi = sMeta[qr];
-    const int lin_i = (int)(mi & 1023u) + c0, reg_i = (int)(mi >> 10);
-    int mx = -2000000000;
+    const float* trow = &sT[wave][(int)(mi & 1023u) + c0];                     // bias entry of key j: trow[-lin_j]
+    const unsigned reg_i = mi >> 10;
+    float xs[4][4];
+    float mx = -3.0e9f;
+    auto scores = [&](auto MASKc) {
+      constexpr bool MASK = decltype(MASKc)::value;                            // shifted windows: pairs from different regions get -100
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
+      for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (WA_DEAD(kb, r)) continue;
-        const int j = kb * 16 + 4 * g + r;
-        const double e = __builtin_fma(sig_d, (double)s1[kb][r], (double)s2[kb][r] * u_d);      // exact
-        const float attn = (float)e;                                                           // ONE rounding
-        const float a1 = __builtin_amdgcn_fmed3f(rintf(attn * inv_sa), -128.f, 127.f);         // qact_attn1
-        const unsigned mj = sMeta[j];
-        const float bc = (float)sT[wave][lin_i - (int)(mj & 1023u)];
-        const float a2 = __builtin_amdgcn_fmed3f(rintf((a1 * a.wa.s_attn + bc * a.wa.s_table) * inv_s2), -128.f, 127.f);   // qact2
-        int xi = (int)a2 - (((int)(mj >> 10) != reg_i) ? m100 : 0);
-        xi = j < N ? xi : -2000000000;
-        s1[kb][r] = xi;
-        mx = xi > mx ? xi : mx;
+        for (int r = 0; r < 4; ++r) {
+          if (WA_DEAD(kb, r)) continue;
+          const double X = __builtin_fma(sig_int, (double)s1[kb][r], (double)s2[kb][r]);         // exact
+          const float a1 = __builtin_amdgcn_fmed3f(rintf((float)X * x_mul), -128.f, 127.f);     // ONE rounding, then qact_attn1
+          const float a2 = __builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(a1, a1_mul, trow[-linj[kb][r]])), -128.f, 127.f);   // qact2
+          float xi = a2;
+          if (MASK) xi -= regj[kb][r] != reg_i ? m100 : 0.f;
+          if (WA_PAD(kb, r)) xi = kb * 16 + 4 * g + r < N ? xi : -3.0e9f;
+          xs[kb][r] = xi;
+          mx = fmaxf(mx, xi);
+        }
       }
-    }
-    {
-      int o = __shfl_xor(mx, 16);
-      mx = o > mx ? o : mx;
-      o = __shfl_xor(mx, 32);
-      mx = o > mx ? o : mx;
-    }
+    };
+    if (a.wa.region) scores(std::integral_constant<bool, true>{});             // wave-uniform
+    else scores(std::integral_constant<bool, false>{});
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
     long long S = 0;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (WA_DEAD(kb, r)) continue;
-        const int j = kb * 16 + 4 * g + r;
-        int d = mx - s1[kb][r];
-        d = d > 256 ? 256 : d;
-        d = j < N ? d : 257;
+        int d = (int)fminf(mx - xs[kb][r], 256.f);                             // integral values: exact
+        if (WA_PAD(kb, r)) d = kb * 16 + 4 * g + r < N ? d : 257;
         s1[kb][r] = d;
         S += lutE[d];
       }
@@ -2236,23 +2261,28 @@ __global__ __launch_bounds__(256, 4) void k_window_attention(WinAttnArgs a) {
       unsigned pk[4];
 #pragma unroll
       for (int e2 = 0; e2 < 4; ++e2) {
-        unsigned hw2[2];
+        float ratio[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int jj = 2 * e2 + e;
           const int kb = 2 * p + (jj >> 2), r = jj & 3;
           if (WA_DEAD(kb, r)) {
-            hw2[e] = 0u;
+            ratio[e] = 4.0e9f;                                             // -> probability 0
             continue;
           }
-          const float ratio = rintf((float)(Sd * lutFR[s1[kb][r]]));       // correctly rounded fp32 quotient, as in k_lis_attention
-          int k = (int)((__float_as_uint(ratio) + 0x00400000u) >> 23) - 127;
-          k = k > 16 ? 16 : k;
-          hw2[e] = (k < 16 && s1[kb][r] != 257) ? (unsigned)(127 - k) << 7 : 0u;
-          if (a.probs_k && qi < N && kb * 16 + 4 * g + r < N)
-            a.probs_k[((((long long)b * nW + w) * a.H + head) * N + qi) * N + kb * 16 + 4 * g + r] = (int8_t)k;
+          // correctly rounded fp32 quotient, as in k_lis_attention; a padding key (entry 257: reciprocal 1) gives sum / 1 >= 2^32 -> k clamps -> 0
+          ratio[e] = rintf((float)(Sd * lutFR[s1[kb][r]]));
+          if (TAP && qi < N && kb * 16 + 4 * g + r < N) {
+            const int k = (int)((__float_as_uint(ratio[e]) + 0x00400000u) >> 23) - 127;
+            a.probs_k[((((long long)b * nW + w) * a.H + head) * N + qi) * N + kb * 16 + 4 * g + r] = (int8_t)(k > 16 ? 16 : k);
+          }
         }
-        pk[e2] = hw2[0] | (hw2[1] << 16);
+        // log_round and the clamp at 16 on the two high halves at once, see k_lis_attention
+        const unsigned hi2 = __builtin_amdgcn_perm(__float_as_uint(ratio[1]), __float_as_uint(ratio[0]), 0x07060302u);
+        const v2u16 eb = __builtin_bit_cast(v2u16, (__builtin_bit_cast(unsigned, __builtin_bit_cast(v2u16, hi2) + (v2u16){0x40, 0x40})) & 0x7F807F80u);
+        const v2u16 hb = (v2u16){0x7F00, 0x7F00} - eb;                                  // (254 - E) << 7
+        const v2i16 neg = __builtin_bit_cast(v2i16, (v2u16)(hb - (v2u16){0x3800, 0x3800})) >> (v2i16){15, 15};   // all ones where k >= 16
+        pk[e2] = __builtin_bit_cast(unsigned, hb) & ~__builtin_bit_cast(unsigned, neg);
       }
       v4i pb = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
       const v8bf fb = __builtin_bit_cast(v8bf, pb);
@@ -2648,8 +2678,13 @@ int p2v_launch_avgpool_quant(const int8_t* x, int B, int T, int C, float s_in, f
 int p2v_launch_window_attention(const WinAttnArgs& a, hipStream_t st) {
   const int hgroups = (a.H + 3) / 4;
   const dim3 grid((unsigned)(a.B * a.wa.n_windows * hgroups));
-  if (a.wa.ws == 7) hipLaunchKernelGGL(k_window_attention<49>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_window_attention<0>, grid, dim3(256), 0, st, a);
+  if (a.wa.ws == 7) {
+    if (a.probs_k) hipLaunchKernelGGL((k_window_attention<49, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_window_attention<49, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (a.probs_k) hipLaunchKernelGGL((k_window_attention<0, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_window_attention<0, false>), grid, dim3(256), 0, st, a);
+  }
   CHECK_LAUNCH();
   return 0;
 }
