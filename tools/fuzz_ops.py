@@ -224,6 +224,11 @@ def winattn_case(i):
     out = torch.zeros(B * T, C_, dtype=torch.int8, device='cuda')
     pk = torch.full((B, nW, heads, N, N), -1, dtype=torch.int8, device='cuda')
     E.check(L.p2v_window_attention(E.ptr(dev['qkv']), B, T, heads, 32, C.byref(wa), E.ptr(out), E.ptr(pk), E.stream_ptr()))
+    out_nt = torch.zeros(B * T, C_, dtype=torch.int8, device='cuda')       # the instantiation without the tap stores
+    E.check(L.p2v_window_attention(E.ptr(dev['qkv']), B, T, heads, 32, C.byref(wa), E.ptr(out_nt), None, E.stream_ptr()))
+    if not torch.equal(out_nt, out):
+        fails += 1
+        print('window attention case %d: output with and without taps differs' % i)
     xw = qkv[:, idx.reshape(-1)].reshape(B * nW, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
     s1 = torch.tensor(c['qact1'])
     qs = (xw[0] * s1) * torch.tensor(32 ** -0.5, dtype=torch.float32)
