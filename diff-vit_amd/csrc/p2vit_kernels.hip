@@ -2096,6 +2096,7 @@ __global__ __launch_bounds__(256, 3) void k_window_attention(WinAttnArgs a) {
   __shared__ __attribute__((aligned(16))) int8_t sK[4][WA_KEYS * WA_HD];
   __shared__ __attribute__((aligned(16))) unsigned short sVt[4][WA_HD * VSTRIDE];
   __shared__ float sT[4][232];                                                // bias-table column of the head ((2*8-1)^2 = 225 max), times s_table / s_q2
+  __shared__ __attribute__((aligned(16))) unsigned short sP[4][4][16];          // NT = 49: probabilities of the lone 49th query, see the tail block
   __shared__ unsigned short sMeta[WA_KEYS + 16];                               // per token: lin (y*(2ws-1)+x) | region << 10
   __shared__ long long lutE[258];
   __shared__ double lutFR[258];                                                // fp64 reciprocal of float(exp_int)
@@ -2107,6 +2108,19 @@ __global__ __launch_bounds__(256, 3) void k_window_attention(WinAttnArgs a) {
   const int head = hg * 4 + wave;
   const int C = a.H * WA_HD;
   const long long ldq = a.wa.qkv_stride ? a.wa.qkv_stride : 3 * C, ldo = a.wa.out_stride ? a.wa.out_stride : C;
+  // The kernel is short (four query blocks per wave) and its global loads form chains (row table -> K / V / Q rows): every load is
+  // requested as early as its address is known and the arithmetic of the tables runs under the latency - row table, region ids and
+  // the bias column first, then the exp table, then K / V and the first Q block, then the LDS stores
+  const bool hok = head < a.H;
+  const bool live = lane < N;
+  const int rowj = a.wa.win_index[w * N + (live ? lane : 0)];                  // row of token `lane` of this window
+  const int tsz = (2 * ws - 1) * (2 * ws - 1);
+  int8_t tcode[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (hok && lane + 64 * i < tsz) tcode[i] = a.wa.table_codes[(lane + 64 * i) * a.H + head];
+  int reg_t = 0;
+  if (a.wa.region && tid < N) reg_t = (int)a.wa.region[w * N + tid];
   // exp table of the log-int-softmax (as in k_lis_attention); entry 256 = clamp value (masked pairs), 257 = padding
   for (int t = tid; t < 258; t += (int)blockDim.x) {
     int xi = -t;
@@ -2124,29 +2138,29 @@ __global__ __launch_bounds__(256, 3) void k_window_attention(WinAttnArgs a) {
   }
   if (tid < WA_KEYS + 16) {
     const int t = tid < N ? tid : 0;
-    const int reg = (a.wa.region && tid < N) ? (int)a.wa.region[w * N + t] : 0;
-    sMeta[tid] = (unsigned short)(((t / ws) * (2 * ws - 1) + (t % ws)) | (reg << 10));
+    sMeta[tid] = (unsigned short)(((t / ws) * (2 * ws - 1) + (t % ws)) | (reg_t << 10));
   }
-  __syncthreads();
-  if (head >= a.H) return;
-  const int tsz = (2 * ws - 1) * (2 * ws - 1);
+  // K rows (int8) and V rows of the window's tokens (rows >= N are zero) and the Q fragment of the first query block
+  const int8_t* hbase = a.qkv + (long long)b * a.T * ldq + head * WA_HD;
+  uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0, v0 = k0, v1 = k0;
+  if (hok && live) {
+    const int8_t* base = hbase + (long long)rowj * ldq;
+    k0 = *reinterpret_cast<const uint4*>(base + C);
+    k1 = *reinterpret_cast<const uint4*>(base + C + 16);
+    v0 = *reinterpret_cast<const uint4*>(base + 2 * C);
+    v1 = *reinterpret_cast<const uint4*>(base + 2 * C + 16);
+  }
+  int rowq_next = __shfl(rowj, l15 < N ? l15 : N - 1);
+  v4i qc_next = {0, 0, 0, 0};
+  if (hok) qc_next = *reinterpret_cast<const v4i*>(hbase + (long long)rowq_next * ldq + (g & 1) * 16);
   const float inv_sa = 1.0f / a.wa.s_attn, inv_s2 = 1.0f / a.wa.s_q2;          // powers of two: exact
   // qact2((a1 * s_attn + code * s_table)) = clamp(rint(fma(a1, s_attn / s_q2, code * s_table / s_q2))): the products are exact (powers of
   // two) and the one rounding of the sum is the reference's, so the bias column is staged already scaled
   const float tb_mul = a.wa.s_table * inv_s2, a1_mul = a.wa.s_attn * inv_s2;
-  for (int t = lane; t < tsz; t += 64) sT[wave][t] = (float)a.wa.table_codes[t * a.H + head] * tb_mul;
-  // stage K rows (int8) and V^T (bf16) of the window's tokens; rows >= N are zero
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (lane + 64 * i < tsz) sT[wave][lane + 64 * i] = (float)tcode[i] * tb_mul;
   {
-    const bool live = lane < N;
-    const int rowj = a.wa.win_index[w * N + (live ? lane : 0)];
-    const int8_t* base = a.qkv + ((long long)b * a.T + rowj) * ldq + head * WA_HD;
-    uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0, v0 = k0, v1 = k0;
-    if (live) {
-      k0 = *reinterpret_cast<const uint4*>(base + C);
-      k1 = *reinterpret_cast<const uint4*>(base + C + 16);
-      v0 = *reinterpret_cast<const uint4*>(base + 2 * C);
-      v1 = *reinterpret_cast<const uint4*>(base + 2 * C + 16);
-    }
     *reinterpret_cast<uint4*>(&sK[wave][lane * WA_HD]) = k0;
     *reinterpret_cast<uint4*>(&sK[wave][lane * WA_HD + 16]) = k1;
     const unsigned vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -2156,6 +2170,8 @@ __global__ __launch_bounds__(256, 3) void k_window_attention(WinAttnArgs a) {
       sVt[wave][c * VSTRIDE + lane] = (unsigned short)(__float_as_uint(f) >> 16);   // exact bf16
     }
   }
+  __syncthreads();
+  if (!hok) return;
   const float sigma = a.wa.s_q1 * a.wa.qk_scale;                               // exact (s_q1 = 2^e)
   const float inv_u = __uint_as_float((unsigned)(254 - (int)(__float_as_uint(sigma) >> 23) + 23) << 23);   // 1 / ulp(sigma)
   // score = u * X,  X = (sigma / u) * S1 + S2 an integer below 2^53 (u = ulp(sigma) * s_q1 of the keys, a power of two): RN32(u * X) = u * RN32(X)
@@ -2180,8 +2196,13 @@ __global__ __launch_bounds__(256, 3) void k_window_attention(WinAttnArgs a) {
   for (int qb = 0; qb < nqb; ++qb) {
     const int qi = qb * 16 + l15;
     const int qr = qi < N ? qi : N - 1;
-    const int rowq = a.wa.win_index[w * N + qr];
-    const v4i qc = *reinterpret_cast<const v4i*>(a.qkv + ((long long)b * a.T + rowq) * ldq + head * WA_HD + (g & 1) * 16);
+    const int rowq = rowq_next;
+    const v4i qc = qc_next;
+    if (qb + 1 < nqb) {                                                        // the next block's Q fragment, a block ahead
+      const int qn = qi + 16 < N ? qi + 16 : N - 1;
+      rowq_next = __shfl(rowj, qn);
+      qc_next = *reinterpret_cast<const v4i*>(hbase + (long long)rowq_next * ldq + (g & 1) * 16);
+    }
     // eta plane: the lanes of g >= 2 need it, and the lane 32 below holds the same sixteen codes - each computes eight (g < 2: dwords 0-1,
     // g >= 2: dwords 2-3) and the lower half hands its two dwords up (v_permlane32_swap).  In units of u: eta = RN32(code * m) - code * m
     // with m = sigma / u, the significand of sigma as an integer (scaling by a power of two commutes with the rounding); the integral
@@ -2216,76 +2237,124 @@ __global__ __launch_bounds__(256, 3) void k_window_attention(WinAttnArgs a) {
     const unsigned mi = sMeta[qr];
     const float* trow = &sT[wave][(int)(mi & 1023u) + c0];                     // bias entry of key j: trow[-lin_j]
     const unsigned reg_i = mi >> 10;
-    float xs[4][4];
-    float mx = -3.0e9f;
-    auto scores = [&](auto MASKc) {
-      constexpr bool MASK = decltype(MASKc)::value;                            // shifted windows: pairs from different regions get -100
+    v4i pb[2];
+    if (NT == 49 && qb == 3) {
+      // The last query block of a 7 x 7 window holds ONE query (the 49th): all sixteen query columns of the score tile are that query, so the
+      // thirteen live score slots of a lane are shared out over its sixteen columns - lane (l15, g) finishes slot l15 only (one chain instead
+      // of thirteen), the row max and the sum run over the 16-lane rows as well, and the probabilities return to the operand layout of the
+      // P.V product through 128 bytes of LDS per wave
+      const int t = l15 < 13 ? l15 : 12;
+      int v1 = s1[0][0], v2 = s2[0][0];
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
+      for (int u = 1; u < 13; ++u) {
+        const int kb = u < 12 ? u >> 2 : 3, r = u < 12 ? u & 3 : 0;
+        v1 = t == u ? s1[kb][r] : v1;
+        v2 = t == u ? s2[kb][r] : v2;
+      }
+      const int j = t < 12 ? (t >> 2) * 16 + 4 * g + (t & 3) : 48 + 4 * g;
+      const bool valid = l15 < 13 && j < N;
+      const unsigned mj = sMeta[j];
+      const double X = __builtin_fma(sig_int, (double)v1, (double)v2);
+      const float a1 = __builtin_amdgcn_fmed3f(rintf((float)X * x_mul), -128.f, 127.f);
+      const float a2 = __builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(a1, a1_mul, trow[-(int)(mj & 1023u)])), -128.f, 127.f);
+      float xi = a2;
+      if (a.wa.region) xi -= (mj >> 10) != reg_i ? m100 : 0.f;
+      xi = valid ? xi : -3.0e9f;
+      float mx = xi;
+#define WA_ROWMAX(ctrl) mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), ctrl, 0xF, 0xF, false)));
+      WA_ROWMAX(0xB1) WA_ROWMAX(0x4E) WA_ROWMAX(0x141) WA_ROWMAX(0x140)          // as half_wave_sum: the 16 lanes of a row
+#undef WA_ROWMAX
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const int d = valid ? (int)fminf(mx - xi, 256.f) : 257;
+      long long S = lutE[d];
+#pragma unroll
+      for (int o_ = 1; o_ < 64; o_ <<= 1) S += __shfl_xor(S, o_);
+      const double Sd = (double)(float)S;
+      const float ratio = rintf((float)(Sd * lutFR[d]));
+      const int E = (int)((__float_as_uint(ratio) + 0x00400000u) >> 23);         // biased exponent of 2^k
+      if (TAP && valid)
+        a.probs_k[((((long long)b * nW + w) * a.H + head) * N + (N - 1)) * N + j] = (int8_t)(E - 127 > 16 ? 16 : E - 127);
+      sP[wave][g][l15] = (unsigned short)((E < 143 && l15 < 13) ? (254 - E) << 7 : 0);     // 2^-k as bf16, 0 from k = 16 (and for padding: sum / 1 >= 2^32)
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      pb[0] = *reinterpret_cast<const v4i*>(&sP[wave][g][0]);                  // slots 0-7 = key blocks 0, 1;  8-15 = key blocks 2, 3 (13-15: zero)
+      pb[1] = *reinterpret_cast<const v4i*>(&sP[wave][g][8]);
+    } else {
+      float xs[4][4];
+      float mx = -3.0e9f;
+      auto scores = [&](auto MASKc) {
+        constexpr bool MASK = decltype(MASKc)::value;                            // shifted windows: pairs from different regions get -100
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (WA_DEAD(kb, r)) continue;
+            const double X = __builtin_fma(sig_int, (double)s1[kb][r], (double)s2[kb][r]);         // exact
+            const float a1 = __builtin_amdgcn_fmed3f(rintf((float)X * x_mul), -128.f, 127.f);     // ONE rounding, then qact_attn1
+            const float a2 = __builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(a1, a1_mul, trow[-linj[kb][r]])), -128.f, 127.f);   // qact2
+            float xi = a2;
+            if (MASK) xi -= regj[kb][r] != reg_i ? m100 : 0.f;
+            if (WA_PAD(kb, r)) xi = kb * 16 + 4 * g + r < N ? xi : -3.0e9f;
+            xs[kb][r] = xi;
+            mx = fmaxf(mx, xi);
+          }
+        }
+      };
+      if (a.wa.region) scores(std::integral_constant<bool, true>{});             // wave-uniform
+      else scores(std::integral_constant<bool, false>{});
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      long long S = 0;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (WA_DEAD(kb, r)) continue;
-          const double X = __builtin_fma(sig_int, (double)s1[kb][r], (double)s2[kb][r]);         // exact
-          const float a1 = __builtin_amdgcn_fmed3f(rintf((float)X * x_mul), -128.f, 127.f);     // ONE rounding, then qact_attn1
-          const float a2 = __builtin_amdgcn_fmed3f(rintf(__builtin_fmaf(a1, a1_mul, trow[-linj[kb][r]])), -128.f, 127.f);   // qact2
-          float xi = a2;
-          if (MASK) xi -= regj[kb][r] != reg_i ? m100 : 0.f;
-          if (WA_PAD(kb, r)) xi = kb * 16 + 4 * g + r < N ? xi : -3.0e9f;
-          xs[kb][r] = xi;
-          mx = fmaxf(mx, xi);
+          int d = (int)fminf(mx - xs[kb][r], 256.f);                             // integral values: exact
+          if (WA_PAD(kb, r)) d = kb * 16 + 4 * g + r < N ? d : 257;
+          s1[kb][r] = d;
+          S += lutE[d];
         }
-      }
-    };
-    if (a.wa.region) scores(std::integral_constant<bool, true>{});             // wave-uniform
-    else scores(std::integral_constant<bool, false>{});
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    long long S = 0;
+      S += __shfl_xor(S, 16);
+      S += __shfl_xor(S, 32);
+      const float Sf = (float)S;
+      const double Sd = (double)Sf;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+      for (int p = 0; p < 2; ++p) {
+        unsigned pk[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (WA_DEAD(kb, r)) continue;
-        int d = (int)fminf(mx - xs[kb][r], 256.f);                             // integral values: exact
-        if (WA_PAD(kb, r)) d = kb * 16 + 4 * g + r < N ? d : 257;
-        s1[kb][r] = d;
-        S += lutE[d];
+        for (int e2 = 0; e2 < 4; ++e2) {
+          float ratio[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int jj = 2 * e2 + e;
+            const int kb = 2 * p + (jj >> 2), r = jj & 3;
+            if (WA_DEAD(kb, r)) {
+              ratio[e] = 4.0e9f;                                             // -> probability 0
+              continue;
+            }
+            // correctly rounded fp32 quotient, as in k_lis_attention; a padding key (entry 257: reciprocal 1) gives sum / 1 >= 2^32 -> k clamps -> 0
+            ratio[e] = rintf((float)(Sd * lutFR[s1[kb][r]]));
+            if (TAP && qi < N && kb * 16 + 4 * g + r < N) {
+              const int k = (int)((__float_as_uint(ratio[e]) + 0x00400000u) >> 23) - 127;
+              a.probs_k[((((long long)b * nW + w) * a.H + head) * N + qi) * N + kb * 16 + 4 * g + r] = (int8_t)(k > 16 ? 16 : k);
+            }
+          }
+          // log_round and the clamp at 16 on the two high halves at once, see k_lis_attention
+          const unsigned hi2 = __builtin_amdgcn_perm(__float_as_uint(ratio[1]), __float_as_uint(ratio[0]), 0x07060302u);
+          const v2u16 eb = __builtin_bit_cast(v2u16, (__builtin_bit_cast(unsigned, __builtin_bit_cast(v2u16, hi2) + (v2u16){0x40, 0x40})) & 0x7F807F80u);
+          const v2u16 hb = (v2u16){0x7F00, 0x7F00} - eb;                                  // (254 - E) << 7
+          const v2i16 neg = __builtin_bit_cast(v2i16, (v2u16)(hb - (v2u16){0x3800, 0x3800})) >> (v2i16){15, 15};   // all ones where k >= 16
+          pk[e2] = __builtin_bit_cast(unsigned, hb) & ~__builtin_bit_cast(unsigned, neg);
+        }
+        pb[p] = (v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
       }
-    S += __shfl_xor(S, 16);
-    S += __shfl_xor(S, 32);
-    const float Sf = (float)S;
-    const double Sd = (double)Sf;
+    }
     v4f o[2] = {(v4f){0.f, 0.f, 0.f, 0.f}, (v4f){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      unsigned pk[4];
-#pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) {
-        float ratio[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int jj = 2 * e2 + e;
-          const int kb = 2 * p + (jj >> 2), r = jj & 3;
-          if (WA_DEAD(kb, r)) {
-            ratio[e] = 4.0e9f;                                             // -> probability 0
-            continue;
-          }
-          // correctly rounded fp32 quotient, as in k_lis_attention; a padding key (entry 257: reciprocal 1) gives sum / 1 >= 2^32 -> k clamps -> 0
-          ratio[e] = rintf((float)(Sd * lutFR[s1[kb][r]]));
-          if (TAP && qi < N && kb * 16 + 4 * g + r < N) {
-            const int k = (int)((__float_as_uint(ratio[e]) + 0x00400000u) >> 23) - 127;
-            a.probs_k[((((long long)b * nW + w) * a.H + head) * N + qi) * N + kb * 16 + 4 * g + r] = (int8_t)(k > 16 ? 16 : k);
-          }
-        }
-        // log_round and the clamp at 16 on the two high halves at once, see k_lis_attention
-        const unsigned hi2 = __builtin_amdgcn_perm(__float_as_uint(ratio[1]), __float_as_uint(ratio[0]), 0x07060302u);
-        const v2u16 eb = __builtin_bit_cast(v2u16, (__builtin_bit_cast(unsigned, __builtin_bit_cast(v2u16, hi2) + (v2u16){0x40, 0x40})) & 0x7F807F80u);
-        const v2u16 hb = (v2u16){0x7F00, 0x7F00} - eb;                                  // (254 - E) << 7
-        const v2i16 neg = __builtin_bit_cast(v2i16, (v2u16)(hb - (v2u16){0x3800, 0x3800})) >> (v2i16){15, 15};   // all ones where k >= 16
-        pk[e2] = __builtin_bit_cast(unsigned, hb) & ~__builtin_bit_cast(unsigned, neg);
-      }
-      v4i pb = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
-      const v8bf fb = __builtin_bit_cast(v8bf, pb);
+      const v8bf fb = __builtin_bit_cast(v8bf, pb[p]);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const unsigned short* vp = &sVt[wave][(dt * 16 + l15) * VSTRIDE + p * 32 + 4 * g];
