@@ -1109,16 +1109,14 @@ __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_g
   }
 }
 
-// One row: packed input codes wcur[i] (0 where the lane's channels lie past C) -> packed output codes outw[i].  Every lane of the
-// row group (32 or 64 lanes) must call it: the sums are cross-lane reductions.
-template <int NCH, int LANES>
-__device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane<NCH>& L, const p2v_ln& ln, int C, int l32, unsigned (&outw)[NCH]) {
-  const float s1 = ln.s1;
-  const float Cf = (float)C;
-  const float s1oC = s1 / Cf;
-  float xq[NCH][4];
-  int S1;
-  unsigned S2 = 0;                              // C * (128*8)^2 <= 2^31 for C <= 2048: exact in 32 unsigned bits
+// The LayerNorm of a row in four steps, shared by the one-row and the batched form below:
+//   ln_sums   the lane's x_q = code * mask and its part of sum x_q, sum x_q^2
+//   ln_reduce the sums over the row group (32 or 64 lanes), result in every lane
+//   ln_scalars mean / std -> the two row scalars rs = s1 / std, mos = mean / std and the fast-chain test
+//   ln_apply  the per-element chain with those scalars -> packed output codes
+template <int NCH>
+__device__ __forceinline__ void ln_sums(const unsigned (&wcur)[NCH], const LnLane<NCH>& L, float (&xq)[NCH][4], int& S1, unsigned& S2) {
+  S2 = 0;                                       // C * (128*8)^2 <= 2^31 for C <= 2048: exact in 32 unsigned bits
 #if defined(P2V_EXP_NOTRIM2) || defined(P2V_EXP_OLDSUMS)
   S1 = 0;
 #pragma unroll
@@ -1152,24 +1150,37 @@ __device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane
   }
   S1 = (int)S1p;
 #endif
+}
+template <int LANES>
+__device__ __forceinline__ void ln_reduce(int& S1, unsigned& S2) {
   S1 = half_wave_sum(S1);
   S2 = (unsigned)half_wave_sum((int)S2);        // two's-complement adds: the unsigned total is exact
   if (LANES == 64) {
     S1 += __shfl_xor(S1, 32);
     S2 += (unsigned)__shfl_xor((int)S2, 32);
   }
+}
+template <int NCH>
+__device__ __forceinline__ void ln_scalars(int S1, unsigned S2, const LnLane<NCH>& L, const p2v_ln& ln, int C, float& rs, float& mos, bool& fast) {
+  const float s1 = ln.s1;
+  const float Cf = (float)C;
+  const float s1oC = s1 / Cf;
   const float S1f = (float)S1, S2f = (float)S2;
   const float mean = (S1f / Cf) * s1;                                  // x_q.mean(-1) * in_scale1
   const float stdv = s1oC * sqrtf(Cf * S2f - S1f * S1f);               // layers.py:276-277
-  const float rs = s1 / stdv;
-  const float mos = mean / stdv;
+  rs = s1 / stdv;
+  mos = mean / stdv;
   // |A| = RN(rs*|g io|) is monotone in |g io|: the two extreme channels bound every channel exactly
   // ... and the offset Bv = rint(t * 2^N) (t = beta*io - mos*gamma*io) is rounded by adding and subtracting 1.5 * 2^(23-N), which is
   // rint on the 2^-N grid (ties to even included) as long as |t| * 2^N < 2^22: |t| <= bmax + |mos| gmax and N <= 134 - exp(rs * gmin),
   // so one comparison per row against 2^(exp(rs*gmin) - 112) bounds every channel (1 % margin for the roundings of t itself)
   const float amin = rs * L.gmin;
   const float tlim = __uint_as_float((((__float_as_uint(amin) >> 23) & 255u) + 15u) << 23);       // 2^22 * 2^-(134 - e_min)
-  const bool fast = L.pot && amin >= 0x1p-24f && rs * L.gmax < 256.f && (L.bmax + fabsf(mos) * L.gmax) * 1.01f < tlim;
+  fast = L.pot && amin >= 0x1p-24f && rs * L.gmax < 256.f && (L.bmax + fabsf(mos) * L.gmax) * 1.01f < tlim;
+}
+template <int NCH, int LANES>
+__device__ __forceinline__ void ln_apply(const float (&xq)[NCH][4], const LnLane<NCH>& L, const p2v_ln& ln, int l32, float rs, float mos, bool fast,
+                                         unsigned (&outw)[NCH]) {
   if (fast) {
     auto chain = [&](auto PM1c) {
       constexpr bool PM1 = decltype(PM1c)::value;
@@ -1232,6 +1243,57 @@ __device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane
   }
 }
 
+// One row: packed input codes wcur[i] (0 where the lane's channels lie past C) -> packed output codes outw[i].  Every lane of the
+// row group (32 or 64 lanes) must call it: the sums are cross-lane reductions.
+template <int NCH, int LANES>
+__device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane<NCH>& L, const p2v_ln& ln, int C, int l32, unsigned (&outw)[NCH]) {
+  float xq[NCH][4], rs, mos;
+  int S1;
+  unsigned S2;
+  bool fast;
+  ln_sums<NCH>(wcur, L, xq, S1, S2);
+  ln_reduce<LANES>(S1, S2);
+  ln_scalars<NCH>(S1, S2, L, ln, C, rs, mos, fast);
+  ln_apply<NCH, LANES>(xq, L, ln, l32, rs, mos, fast, outw);
+}
+
+// R rows of a row group at once (round 3).  The row scalars - three IEEE divisions, a square root and the range tests, ~55 instructions
+// that every lane of the group would repeat per row - are computed ONCE for the R rows: lane l keeps the sums of row (l mod R), runs the
+// scalar chain on them, and row r's results are read back from lane r of the group (ds_bpermute).  Same operations on the same values
+// as ln_row, only in other lanes: bit-identical.
+template <int NCH, int LANES, int R>
+__device__ __forceinline__ void ln_rows(const unsigned (&wcur)[R][NCH], const LnLane<NCH>& L, const p2v_ln& ln, int C, int l32, unsigned (&outw)[R][NCH]) {
+  static_assert((R & (R - 1)) == 0 && R <= 8, "rows per batch");
+  float xq[R][NCH][4];
+  int S1k = 0;
+  unsigned S2k = 0;
+  const int mine = l32 & (R - 1);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    int S1;
+    unsigned S2;
+    ln_sums<NCH>(wcur[r], L, xq[r], S1, S2);
+    ln_reduce<LANES>(S1, S2);
+    S1k = mine == r ? S1 : S1k;
+    S2k = mine == r ? S2 : S2k;
+  }
+  float rs, mos;
+  bool fast;
+  ln_scalars<NCH>(S1k, S2k, L, ln, C, rs, mos, fast);
+  const int fasti = fast ? 1 : 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float rs_r = __shfl(rs, r, LANES), mos_r = __shfl(mos, r, LANES);
+    const bool fast_r = __shfl(fasti, r, LANES) != 0;
+    ln_apply<NCH, LANES>(xq[r], L, ln, l32, rs_r, mos_r, fast_r, outw[r]);
+  }
+}
+
+// rows per batch in the stand-alone kernel: 1 - two rows (ln_rows) cost 23 more VGPRs, i.e. the third wave per SIMD at C = 384 and 768, and
+// measured 9 % / 6 % slower there; the fused kernels, whose LayerNorm phase has registers to spare, take their rows in pairs
+#ifndef LN_BATCH
+#define LN_BATCH 1
+#endif
 template <int NCH, int LANES>
 __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
   // per-channel constants are folded once per workgroup, shared through LDS, then held in registers (re-reading them from
@@ -1250,33 +1312,48 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
 #pragma unroll
   for (int i = 0; i < NCH; ++i) colofs[i] = L.on[i] ? (l32 + LANES * i) * 4 : 0;     // clamped: loads are unconditional
   const long long last_row = a.rows - 1;
-  unsigned wnext[NCH];
+  constexpr int R = LN_BATCH;                                      // rows per batch of ln_rows (the row scalars are computed once per batch)
+  unsigned wnext[R][NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i)
-    wnext[i] = *reinterpret_cast<const unsigned*>(a.x + (row0 < a.rows ? row0 : last_row) * a.row_stride + colofs[i]);
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(wnext[i]));   // first row landed: no wait is merged into the loop head
-#pragma unroll 1
-  for (int rr = 0; rr < LN_ROWS; ++rr) {
-    const long long row = row0 + rr;
-    if (row >= a.rows) break;   // uniform within the half wave; the reductions below stay inside 32 lanes
-    unsigned wcur[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) wcur[i] = L.on[i] ? wnext[i] : 0u;
-    {
-      const long long nrow = row + 1 < a.rows ? row + 1 : last_row;
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) wnext[i] = *reinterpret_cast<const unsigned*>(a.x + nrow * a.row_stride + colofs[i]);
-      asm volatile("" ::: "memory");                 // the loads stay above this line
-    }
-    unsigned outw[NCH];
-    ln_row<NCH, LANES>(wcur, L, a.ln, a.C, l32, outw);
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(wnext[i]));   // the wait for row r+1 lands here, ahead of the stores
-    int8_t* dst = a.out + row * a.out_stride;
+  for (int u = 0; u < R; ++u)
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
-      if (L.on[i]) *reinterpret_cast<unsigned*>(dst + (l32 + LANES * i) * 4) = outw[i];
+      wnext[u][i] = *reinterpret_cast<const unsigned*>(a.x + (row0 + u < a.rows ? row0 + u : last_row) * a.row_stride + colofs[i]);
+#pragma unroll
+  for (int u = 0; u < R; ++u)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(wnext[u][i]));   // first rows landed: no wait is merged into the loop head
+#pragma unroll 1
+  for (int rr = 0; rr < LN_ROWS; rr += R) {
+    const long long row = row0 + rr;
+    if (row >= a.rows) break;   // uniform within the row group; the reductions below stay inside it
+    unsigned wcur[R][NCH];
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) wcur[u][i] = L.on[i] ? wnext[u][i] : 0u;
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const long long nrow = row + R + u < a.rows ? row + R + u : last_row;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) wnext[u][i] = *reinterpret_cast<const unsigned*>(a.x + nrow * a.row_stride + colofs[i]);
+    }
+    asm volatile("" ::: "memory");                 // the loads stay above this line
+    unsigned outw[R][NCH];
+    if constexpr (R == 1) ln_row<NCH, LANES>(wcur[0], L, a.ln, a.C, l32, outw[0]);
+    else ln_rows<NCH, LANES, R>(wcur, L, a.ln, a.C, l32, outw);
+#pragma unroll
+    for (int u = 0; u < R; ++u)
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(wnext[u][i]));   // the wait for the next rows lands here, ahead of the stores
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if (rr + u >= LN_ROWS || row + u >= a.rows) continue;
+      int8_t* dst = a.out + (row + u) * a.out_stride;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+        if (L.on[i]) *reinterpret_cast<unsigned*>(dst + (l32 + LANES * i) * 4) = outw[u][i];
+    }
   }
 }
 
@@ -1396,13 +1473,16 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
         load_row(r + 2, wnext[0]);
         load_row(r + 3, wnext[1]);
       }
+      unsigned wcur[2][NCH], outw2[2][NCH];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) wcur[u][i] = L.on[i] ? win[u][i] : 0u;
+      ln_rows<NCH, 32, 2>(wcur, L, a.ln, C, l31, outw2);              // the pair shares one pass of the row-scalar arithmetic
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int lrow = hw * RPH + r + u;
-        unsigned wcur[NCH], outw[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) wcur[i] = L.on[i] ? win[u][i] : 0u;
-        ln_row<NCH, 32>(wcur, L, a.ln, C, l31, outw);
+        const unsigned (&outw)[NCH] = outw2[u];
         const long long row = (long long)m0 + lrow;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -1491,6 +1571,9 @@ __host__ __device__ constexpr int lg2_mfma_at(int hp) {
 
 // EPI: P2V_EPI_REQUANT or P2V_EPI_GELU_TAB;  KT = k-tiles of 64 channels (C <= 64*KT);  NG = wave groups (1: 4 waves, every wave all
 // column tiles, two workgroups per CU; 2: 8 waves, the groups alternate column tiles, one workgroup per CU)
+#ifndef LG2_LN_ROWS
+#define LG2_LN_ROWS 2   /* 4 spills at C = 384 (196 B of scratch): 89.4 k against 98.6 k img/s */
+#endif
 template <int EPI, int KT, int NG, bool W4>
 __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) {
   typedef typename LgW<W4>::raw wraw;
@@ -1547,9 +1630,11 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
       w[i] = *reinterpret_cast<const unsigned*>(rp + (c < C ? c : 0));
     }
   };
-  unsigned win[2][NCH];
-  load_row(0, win[0]);
-  load_row(1, win[1]);
+  constexpr int LR = LG2_LN_ROWS < RPH ? LG2_LN_ROWS : RPH;             // rows per LayerNorm batch (ln_rows)
+  static_assert(RPH % LR == 0, "rows are processed in batches");
+  unsigned win[LR][NCH];
+#pragma unroll
+  for (int u = 0; u < LR; ++u) load_row(u, win[u]);
   // ---- per-column constants of the whole layer (REQUANT: 2^e folded in, see gemm_stage_epilogue) and the GELU table
   {
     const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : 1.0f;
@@ -1576,19 +1661,22 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
     ln_prepare<NCH, 32>(a.ln, C, a.force_generic != 0, sG, sB, sP, sM, tid, NT, L);
     __syncthreads();        // every lane holds its folded constants in registers: the scratch (= the panel) may be overwritten
 #pragma unroll 1
-    for (int r = 0; r < RPH; r += 2) {
-      unsigned wnext[2][NCH];
-      if (r + 2 < RPH) {
-        load_row(r + 2, wnext[0]);
-        load_row(r + 3, wnext[1]);
+    for (int r = 0; r < RPH; r += LR) {
+      unsigned wnext[LR][NCH];
+      if (r + LR < RPH) {
+#pragma unroll
+        for (int u = 0; u < LR; ++u) load_row(r + LR + u, wnext[u]);
       }
+      unsigned wcur[LR][NCH], outw2[LR][NCH];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < LR; ++u)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) wcur[u][i] = L.on[i] ? win[u][i] : 0u;
+      ln_rows<NCH, 32, LR>(wcur, L, a.ln, C, l31, outw2);             // the batch shares one pass of the row-scalar arithmetic
+#pragma unroll
+      for (int u = 0; u < LR; ++u) {
         const int lrow = hw * RPH + r + u;
-        unsigned wcur[NCH], outw[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) wcur[i] = L.on[i] ? win[u][i] : 0u;
-        ln_row<NCH, 32>(wcur, L, a.ln, C, l31, outw);
+        const unsigned (&outw)[NCH] = outw2[u];
         const long long row = (long long)m0 + lrow;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -1599,12 +1687,11 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
           if (a.out && L.on[i] && row < a.rows) *reinterpret_cast<unsigned*>(a.out + row * a.out_stride + c) = outw[i];
         }
       }
-      if (r + 2 < RPH) {
+      if (r + LR < RPH) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-          win[0][i] = wnext[0][i];
-          win[1][i] = wnext[1][i];
-        }
+        for (int u = 0; u < LR; ++u)
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) win[u][i] = wnext[u][i];
       }
     }
   }
