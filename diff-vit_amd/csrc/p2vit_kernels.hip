@@ -854,34 +854,45 @@ __global__ __launch_bounds__(128 * MT, MT == 4 ? 4 : (NST == 2 ? 4 : 3)) void k_
   int mra = m0 + ra, mrb = m0 + rb;
   mra = mra < g.M ? mra : g.M - 1;
   mrb = mrb < g.M ? mrb : g.M - 1;
-  const int8_t* gxa = g.A + (long long)mra * g.lda + ((pc ^ ((ra >> 2) & 3)) << 4);
-  const int8_t* gxb = g.A + (long long)mrb * g.lda + ((pc ^ ((rb >> 2) & 3)) << 4);
+  // source = wave-uniform base (the matrix + the k offset: scalar registers) + this lane's 32-bit byte offset, the form the LDS-DMA load
+  // takes as  saddr + zext(voffset): no 64-bit address arithmetic per k-tile (eight v_lshl_add_u64 per wave and k-tile before; the launcher
+  // checks that both matrices stay below 4 GB)
+  const unsigned gxa = (unsigned)mra * (unsigned)g.lda + ((pc ^ ((ra >> 2) & 3)) << 4);
+  const unsigned gxb = (unsigned)mrb * (unsigned)g.lda + ((pc ^ ((rb >> 2) & 3)) << 4);
   const int wa = (MT == 4 ? 16 * wave : 32 * wave) + lr, wb = wa + 16;
-  const int8_t* gwa = g.W + (long long)(n0 + wa) * g.K + ((pc ^ ((wa >> 2) & 3)) << 4);
-  const int8_t* gwb = g.W + (long long)(n0 + wb) * g.K + ((pc ^ ((wb >> 2) & 3)) << 4);
+  const unsigned gwa = (unsigned)(n0 + wa) * (unsigned)g.K + ((pc ^ ((wa >> 2) & 3)) << 4);
+  const unsigned gwb = (unsigned)(n0 + wb) * (unsigned)g.K + ((pc ^ ((wb >> 2) & 3)) << 4);
   // packed int4: the W tile of k-tile kt is the contiguous 4 KB LDS image (tn * nk + kt): one coalesced 1 KB piece per wave (MT = 2);
   // with 8 waves each wave moves 512 bytes (its lower 32 lanes)
-  const int8_t* gw4 = g.W + (long long)tn * (g.K / GBK) * 4096 + (MT == 4 ? wave * 512 + (lane & 31) * 16 : wave * 1024 + lane * 16);
+  const unsigned gw4 = (unsigned)tn * (unsigned)(g.K / GBK) * 4096u + (MT == 4 ? wave * 512 + (lane & 31) * 16 : wave * 1024 + lane * 16);
   auto dma = [&](int stage, int kt) {
     int8_t* dst = lds + stage * STAGE + wave * (32 * GBK);
     const int ko = kt * GBK;
-#define P2V_DMA16_(SRC, DST) \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
-    P2V_DMA16_(gxa + ko, dst);
-    P2V_DMA16_(gxb + ko, dst + 16 * GBK);
+    // written as assembly: hipcc folds  uniform + zext(lane offset)  back into 64-bit vector additions (two v_lshl_add_u64 per request);
+    // the LDS destination of a request is M0 + 16 * lane
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#define P2V_DMA16_(SBASE, VOFF, DST)                                                                                         \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"   /* (one wait state between the M0 write and its use) */ \
+                 :: "v"(VOFF), "s"(SBASE), "s"((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(DST)) : "memory", "m0")
+    const int8_t* xk = g.A + ko;                              // uniform
+    const int8_t* wk = g.W + (W4 ? kt * 4096 : ko);
+    P2V_DMA16_(xk, gxa, dst);
+    P2V_DMA16_(xk, gxb, dst + 16 * GBK);
     if (W4) {
       if (MT == 4) {
-        if (lane < 32) P2V_DMA16_(gw4 + (long long)kt * 4096, lds + stage * STAGE + TBM * GBK + wave * 512);
+        if (lane < 32) P2V_DMA16_(wk, gw4, lds + stage * STAGE + TBM * GBK + wave * 512);
       } else {
-        P2V_DMA16_(gw4 + (long long)kt * 4096, lds + stage * STAGE + TBM * GBK + wave * 1024);
+        P2V_DMA16_(wk, gw4, lds + stage * STAGE + TBM * GBK + wave * 1024);
       }
     } else if (MT == 4) {
-      P2V_DMA16_(gwa + ko, lds + stage * STAGE + TBM * GBK + wave * (16 * GBK));
+      P2V_DMA16_(wk, gwa, lds + stage * STAGE + TBM * GBK + wave * (16 * GBK));
     } else {
-      P2V_DMA16_(gwa + ko, dst + TBM * GBK);
-      P2V_DMA16_(gwb + ko, dst + TBM * GBK + 16 * GBK);
+      P2V_DMA16_(wk, gwa, dst + TBM * GBK);
+      P2V_DMA16_(wk, gwb, dst + TBM * GBK + 16 * GBK);
     }
 #undef P2V_DMA16_
+#pragma clang diagnostic pop
   };
   const int nk = g.K / GBK;
   GD_STAMP(0);
@@ -1736,8 +1747,10 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
   // one per half-piece into accn (X fragments one k-step ahead); with LD the W fragment of the tile after next replaces the one
   // an MFMA pair has just consumed.
   v4i wcur = {0, 0, 0, 0};                                               // the widened fragment between the two MFMAs of a k-step
-  auto tile_body = [&](auto MFc, auto LDc, int j, const wraw* wnn) {
-    constexpr bool MF = decltype(MFc)::value, LD = decltype(LDc)::value;
+  // acc_ / accn_: the accumulators of this tile / of the next one.  The steady-state loop runs the body twice per turn with the two sets
+  // exchanged instead of copying 32 registers per tile (COPY = false); the odd tile and the two tail forms copy the next set into the first
+  auto tile_body = [&](auto MFc, auto LDc, auto COPYc, int j, const wraw* wnn, v16i (&acc)[2], v16i (&accn)[2]) {
+    constexpr bool MF = decltype(MFc)::value, LD = decltype(LDc)::value, COPY = decltype(COPYc)::value;
     const float* cst = consts + j * 2 * GBN + 32 * cw + 4 * h;           // colscale of this wave's columns; bias at + GBN
     const int n_tile = j * GBN + 32 * cw;
     unsigned d[2][4];
@@ -1837,7 +1850,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
       if (m < g.M && n_tile + 16 * h < g.N)
         *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)m * g.ldo + n_tile + 16 * h) = o;
     }
-    if constexpr (MF) {
+    if constexpr (MF && COPY) {
       acc[0] = accn[0];
       acc[1] = accn[1];
     }
@@ -1845,16 +1858,23 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
   int it = 0;
-  for (; it + 2 < n_g; ++it) {
-    tile_body(T_{}, T_{}, grp + NG * it, wtile(it + 2));
+  for (; it + 3 < n_g; it += 2) {
+    tile_body(T_{}, T_{}, F_{}, grp + NG * it, wtile(it + 2), acc, accn);
     LG_STAMP(5 + it);
+    tile_body(T_{}, T_{}, F_{}, grp + NG * (it + 1), wtile(it + 3), accn, acc);
+    LG_STAMP(6 + it);
   }
-  if (it + 1 < n_g) {
-    tile_body(T_{}, F_{}, grp + NG * it, wsrc);
+  if (it + 2 < n_g) {
+    tile_body(T_{}, T_{}, T_{}, grp + NG * it, wtile(it + 2), acc, accn);
     LG_STAMP(5 + it);
     ++it;
   }
-  tile_body(F_{}, F_{}, grp + NG * it, wsrc);
+  if (it + 1 < n_g) {
+    tile_body(T_{}, F_{}, T_{}, grp + NG * it, wsrc, acc, accn);
+    LG_STAMP(5 + it);
+    ++it;
+  }
+  tile_body(F_{}, F_{}, T_{}, grp + NG * it, wsrc, acc, accn);
   LG_STAMP(5 + it);
 #undef LG2_XOFF
 }
@@ -2569,6 +2589,8 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
 #endif
   g.tiles_n = (g.N + GBN - 1) / GBN;
   if (epi != P2V_EPI_HEAD && epi != P2V_EPI_EMBED) {
+    // the tiled kernel addresses both matrices with 32-bit lane offsets
+    if ((long long)g.M * g.lda + g.K >= (1LL << 32) || (long long)g.tiles_n * GBN * g.K >= (1LL << 32)) return -1;
     // 256-row tiles (8 waves, two workgroups per CU) when the grid still gives every CU its two workgroups; else 128-row tiles
     const long long tiles256 = (long long)((g.M + 255) / 256) * g.tiles_n;
     // (packed int4 weights keep 128 rows: the 8-wave form moves a 4 KB W tile as eight half-wave pieces and measured 3 % slower on DeiT-B W4)
