@@ -1030,22 +1030,31 @@ __device__ __forceinline__ float ln_elem_generic(float xq, float g, float bta, f
 // 2^-N commutes with the rounding.  Bit-identical to the generic chain (tests drive both through P2V_LN_GENERIC=1).
 // LANES = 32: one row per half wave (C <= 1024);  LANES = 64: one row per wave (PatchMerging rows of up to 2048 channels)
 // per-lane view of the folded per-channel constants of a LayerNorm (held in registers across rows)
-template <int NCH>
+// LDSC: post_mul and the PTF mask are re-read from the workgroup's LDS copy where they are used (one ds_read_b128 per four channels and
+// row) instead of living in 8 * NCH registers - the stand-alone kernel, whose scratch stays valid, then fits two rows per batch (ln_rows)
+// in the register budget of three waves per SIMD
+template <int NCH, bool LDSC = false>
 struct LnLane {
   bool on[NCH];
-  float4 gm[NCH], bt[NCH], pm[NCH];   // gamma*io, beta*io, post_mul
-  float4 mkf[NCH];                    // PTF mask (in_scale / s1): 1, 2, 4 or 8
+  float4 gm[NCH], bt[NCH];            // gamma*io, beta*io
+  float4 pm[LDSC ? 1 : NCH];          // post_mul
+  float4 mkf[LDSC ? 1 : NCH];         // PTF mask (in_scale / s1): 1, 2, 4 or 8
+  const float* sPl;                   // LDSC: this lane's first four channels in the LDS copies, and the chunk stride in floats
+  const float* sMl;
+  int cstride;
   float gmin, gmax;                   // extreme |gamma*io| over all channels
   float bmax;                         // max |beta*io| over all channels (bound of the LayerNorm offset, see ln_row)
   bool pot;                           // 1/out_scale is a power of two for every channel and the fold is exact
   bool pm_one;                        // post_mul == 1 for every channel (norm1 of P2-ViT: out_scale / channel_scale / qact0 scale): no second requant
+  __device__ __forceinline__ float4 post4(int i) const { return LDSC ? *reinterpret_cast<const float4*>(sPl + i * cstride) : pm[LDSC ? 0 : i]; }
+  __device__ __forceinline__ float4 mask4(int i) const { return LDSC ? *reinterpret_cast<const float4*>(sMl + i * cstride) : mkf[LDSC ? 0 : i]; }
 };
 
 // Fold, test and publish the per-channel constants once per workgroup (every thread calls it; contains a barrier), then load this
 // lane's channels: lane l of a row group owns channels (l + LANES*i)*4 .. +3.
-template <int NCH, int LANES>
+template <int NCH, int LANES, class LL>
 __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_generic, float* sG, float* sB, float* sP, int* sM,
-                                           int tid, int nthreads, LnLane<NCH>& L) {
+                                           int tid, int nthreads, LL& L) {
   const int l32 = tid & (LANES - 1);
   int potf = force_generic ? 0 : 1, pm1 = 1;
   for (int t4 = tid; t4 < NCH * LANES; t4 += nthreads) {   // one thread per 4 channels: fold, test, and publish
@@ -1093,13 +1102,18 @@ __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_g
     L.gm[i] = gv;
     L.bt[i] = *reinterpret_cast<const float4*>(sB + c);
     if (L.on[i]) bmax = fmaxf(bmax, fmaxf(fmaxf(fabsf(L.bt[i].x), fabsf(L.bt[i].y)), fmaxf(fabsf(L.bt[i].z), fabsf(L.bt[i].w))));
-    L.pm[i] = *reinterpret_cast<const float4*>(sP + c);
-    L.mkf[i] = *reinterpret_cast<const float4*>(sM + c);
+    if constexpr (sizeof(L.pm) == sizeof(float4) * NCH) {          // (the register-resident form)
+      L.pm[i] = *reinterpret_cast<const float4*>(sP + c);
+      L.mkf[i] = *reinterpret_cast<const float4*>(sM + c);
+    }
     const float lo = fminf(fminf(fabsf(gv.x), fabsf(gv.y)), fminf(fabsf(gv.z), fabsf(gv.w)));
     const float hi = fmaxf(fmaxf(fabsf(gv.x), fabsf(gv.y)), fmaxf(fabsf(gv.z), fabsf(gv.w)));
     gmin = fminf(gmin, L.on[i] ? lo : 3.0e38f);
     gmax = fmaxf(gmax, L.on[i] ? hi : 0.f);
   }
+  L.sPl = sP + l32 * 4;
+  L.sMl = reinterpret_cast<const float*>(sM) + l32 * 4;
+  L.cstride = LANES * 4;
   {   // positive floats order like their bit patterns: integer min/max butterflies inside the half wave
     int lo = (int)__float_as_uint(gmin), hi = (int)__float_as_uint(gmax), bh = (int)__float_as_uint(bmax);
 #define LN_MM(ctrl) lo = min(lo, __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false)); hi = max(hi, __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false)); \
@@ -1125,15 +1139,16 @@ __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_g
 //   ln_reduce the sums over the row group (32 or 64 lanes), result in every lane
 //   ln_scalars mean / std -> the two row scalars rs = s1 / std, mos = mean / std and the fast-chain test
 //   ln_apply  the per-element chain with those scalars -> packed output codes
-template <int NCH>
-__device__ __forceinline__ void ln_sums(const unsigned (&wcur)[NCH], const LnLane<NCH>& L, float (&xq)[NCH][4], int& S1, unsigned& S2) {
+template <int NCH, class LL>
+__device__ __forceinline__ void ln_sums(const unsigned (&wcur)[NCH], const LL& L, float (&xq)[NCH][4], int& S1, unsigned& S2) {
   S2 = 0;                                       // C * (128*8)^2 <= 2^31 for C <= 2048: exact in 32 unsigned bits
 #if defined(P2V_EXP_NOTRIM2) || defined(P2V_EXP_OLDSUMS)
   S1 = 0;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const unsigned w = wcur[i];
-    const int m4[4] = {(int)L.mkf[i].x, (int)L.mkf[i].y, (int)L.mkf[i].z, (int)L.mkf[i].w};
+    const float4 mk_ = L.mask4(i);
+    const int m4[4] = {(int)mk_.x, (int)mk_.y, (int)mk_.z, (int)mk_.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int v = __mul24(sx8(w, j), m4[j]);           // x_q * in_scale_mask  (layers.py:269-273); w == 0 past C
@@ -1149,7 +1164,8 @@ __device__ __forceinline__ void ln_sums(const unsigned (&wcur)[NCH], const LnLan
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const unsigned w = wcur[i];
-    const float m4[4] = {L.mkf[i].x, L.mkf[i].y, L.mkf[i].z, L.mkf[i].w};
+    const float4 mk_ = L.mask4(i);
+    const float m4[4] = {mk_.x, mk_.y, mk_.z, mk_.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) xq[i][j] = (float)sx8(w, j) * m4[j];       // x_q * in_scale_mask  (layers.py:269-273), exact; w == 0 past C
     S1p += (xq[i][0] + xq[i][1]) + (xq[i][2] + xq[i][3]);                  // (short dependency chains: a wave may be alone on its SIMD)
@@ -1171,8 +1187,8 @@ __device__ __forceinline__ void ln_reduce(int& S1, unsigned& S2) {
     S2 += (unsigned)__shfl_xor((int)S2, 32);
   }
 }
-template <int NCH>
-__device__ __forceinline__ void ln_scalars(int S1, unsigned S2, const LnLane<NCH>& L, const p2v_ln& ln, int C, float& rs, float& mos, bool& fast) {
+template <int NCH, class LL>
+__device__ __forceinline__ void ln_scalars(int S1, unsigned S2, const LL& L, const p2v_ln& ln, int C, float& rs, float& mos, bool& fast) {
   const float s1 = ln.s1;
   const float Cf = (float)C;
   const float s1oC = s1 / Cf;
@@ -1189,8 +1205,8 @@ __device__ __forceinline__ void ln_scalars(int S1, unsigned S2, const LnLane<NCH
   const float tlim = __uint_as_float((((__float_as_uint(amin) >> 23) & 255u) + 15u) << 23);       // 2^22 * 2^-(134 - e_min)
   fast = L.pot && amin >= 0x1p-24f && rs * L.gmax < 256.f && (L.bmax + fabsf(mos) * L.gmax) * 1.01f < tlim;
 }
-template <int NCH, int LANES>
-__device__ __forceinline__ void ln_apply(const float (&xq)[NCH][4], const LnLane<NCH>& L, const p2v_ln& ln, int l32, float rs, float mos, bool fast,
+template <int NCH, int LANES, class LL>
+__device__ __forceinline__ void ln_apply(const float (&xq)[NCH][4], const LL& L, const p2v_ln& ln, int l32, float rs, float mos, bool fast,
                                          unsigned (&outw)[NCH]) {
   if (fast) {
     auto chain = [&](auto PM1c) {
@@ -1198,7 +1214,11 @@ __device__ __forceinline__ void ln_apply(const float (&xq)[NCH][4], const LnLane
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const float g4[4] = {L.gm[i].x, L.gm[i].y, L.gm[i].z, L.gm[i].w}, b4[4] = {L.bt[i].x, L.bt[i].y, L.bt[i].z, L.bt[i].w};
-        const float p4[4] = {L.pm[i].x, L.pm[i].y, L.pm[i].z, L.pm[i].w};
+        float p4[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (!PM1) {
+          const float4 pm_ = L.post4(i);
+          p4[0] = pm_.x; p4[1] = pm_.y; p4[2] = pm_.z; p4[3] = pm_.w;
+        }
         float q[4];
 #pragma unroll
         for (int j = 0; j < 4; j += 2) {   // two channels at a time: only the 3-source fma is packed (measured on gfx950, tools/ubench/valu_rate:
@@ -1256,8 +1276,8 @@ __device__ __forceinline__ void ln_apply(const float (&xq)[NCH][4], const LnLane
 
 // One row: packed input codes wcur[i] (0 where the lane's channels lie past C) -> packed output codes outw[i].  Every lane of the
 // row group (32 or 64 lanes) must call it: the sums are cross-lane reductions.
-template <int NCH, int LANES>
-__device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane<NCH>& L, const p2v_ln& ln, int C, int l32, unsigned (&outw)[NCH]) {
+template <int NCH, int LANES, class LL>
+__device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LL& L, const p2v_ln& ln, int C, int l32, unsigned (&outw)[NCH]) {
   float xq[NCH][4], rs, mos;
   int S1;
   unsigned S2;
@@ -1272,8 +1292,8 @@ __device__ __forceinline__ void ln_row(const unsigned (&wcur)[NCH], const LnLane
 // that every lane of the group would repeat per row - are computed ONCE for the R rows: lane l keeps the sums of row (l mod R), runs the
 // scalar chain on them, and row r's results are read back from lane r of the group (ds_bpermute).  Same operations on the same values
 // as ln_row, only in other lanes: bit-identical.
-template <int NCH, int LANES, int R>
-__device__ __forceinline__ void ln_rows(const unsigned (&wcur)[R][NCH], const LnLane<NCH>& L, const p2v_ln& ln, int C, int l32, unsigned (&outw)[R][NCH]) {
+template <int NCH, int LANES, int R, class LL>
+__device__ __forceinline__ void ln_rows(const unsigned (&wcur)[R][NCH], const LL& L, const p2v_ln& ln, int C, int l32, unsigned (&outw)[R][NCH]) {
   static_assert((R & (R - 1)) == 0 && R <= 8, "rows per batch");
   float xq[R][NCH][4];
   int S1k = 0;
@@ -1300,10 +1320,13 @@ __device__ __forceinline__ void ln_rows(const unsigned (&wcur)[R][NCH], const Ln
   }
 }
 
-// rows per batch in the stand-alone kernel: 1 - two rows (ln_rows) cost 23 more VGPRs, i.e. the third wave per SIMD at C = 384 and 768, and
-// measured 9 % / 6 % slower there; the fused kernels, whose LayerNorm phase has registers to spare, take their rows in pairs
+// rows per batch in the stand-alone kernel: with every constant in registers two rows cost 23 more VGPRs, i.e. the third wave per SIMD at
+// C = 384 and 768 (measured 9 % / 6 % slower); with post_mul and the mask left in LDS (LN_LDSC) the pair fits
 #ifndef LN_BATCH
-#define LN_BATCH 1
+#define LN_BATCH 2
+#endif
+#ifndef LN_LDSC
+#define LN_LDSC true
 #endif
 template <int NCH, int LANES>
 __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
@@ -1312,7 +1335,7 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
   __shared__ __attribute__((aligned(16))) float sG[NCH * LANES * 4], sB[NCH * LANES * 4], sP[NCH * LANES * 4];
   __shared__ __attribute__((aligned(16))) int sM[NCH * LANES * 4];
   const int tid = threadIdx.x, l32 = tid & (LANES - 1), hw = tid / LANES;   // l32: lane within the row group
-  LnLane<NCH> L;
+  LnLane<NCH, LN_LDSC> L;
   ln_prepare<NCH, LANES>(a.ln, a.C, a.force_generic != 0, sG, sB, sP, sM, tid, 256, L);
   const int LN_ROWS = a.rows_per_half;
   const long long row0 = ((long long)blockIdx.x * (256 / LANES) + hw) * LN_ROWS;
