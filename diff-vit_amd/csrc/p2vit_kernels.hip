@@ -771,7 +771,7 @@ __global__ __launch_bounds__(256) void k_embed_fp32(const float* __restrict__ im
 // ---------------------------------------------------------------------------------------------------
 #define DMA_STAGE_BYTES (2 * GBM * GBK)     // 16 KB: X tile + W tile of the 128 x 128 form (a packed int4 W tile fills half of its 8 KB)
 // packed int4 weights: the W fragments are 8-byte reads of the [128][32 B] tile image, widened in registers (unpack_w4)
-template <int OFF>
+template <int OFF, bool FIRST = false>      // FIRST: the tile's first k-tile starts the sums (C operand = the literal 0: no accumulator clearing)
 __device__ __forceinline__ void gemm_compute_tile_dma_w4(unsigned aX0, unsigned aX1, unsigned aW0, unsigned aW1, v16i (&acc)[2][2]) {
   v4i x0a, x1a, x0b, x1b;
   v2u p0a, p1a, p0b, p1b;
@@ -784,10 +784,10 @@ __device__ __forceinline__ void gemm_compute_tile_dma_w4(unsigned aX0, unsigned 
       : "v"(aW0), "v"(aW1), "v"(aX0), "v"(aX1), "v"(bW0), "v"(bW1), "v"(bX0), "v"(bX1), "i"(OFF)
       : "memory");
   const v4i w0a = unpack_w4(p0a[0], p0a[1]), w1a = unpack_w4(p1a[0], p1a[1]);
-  acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0a, x0a, acc[0][0], 0, 0, 0);
-  acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0a, x1a, acc[0][1], 0, 0, 0);
-  acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1a, x0a, acc[1][0], 0, 0, 0);
-  acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1a, x1a, acc[1][1], 0, 0, 0);
+  acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0a, x0a, FIRST ? (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[0][0], 0, 0, 0);
+  acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0a, x1a, FIRST ? (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[0][1], 0, 0, 0);
+  acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1a, x0a, FIRST ? (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[1][0], 0, 0, 0);
+  acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1a, x1a, FIRST ? (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[1][1], 0, 0, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p0b), "+v"(p1b), "+v"(x0b), "+v"(x1b));
   const v4i w0b = unpack_w4(p0b[0], p0b[1]), w1b = unpack_w4(p1b[0], p1b[1]);
   acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0b, x0b, acc[0][0], 0, 0, 0);
@@ -795,7 +795,7 @@ __device__ __forceinline__ void gemm_compute_tile_dma_w4(unsigned aX0, unsigned 
   acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1b, x0b, acc[1][0], 0, 0, 0);
   acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1b, x1b, acc[1][1], 0, 0, 0);
 }
-template <int OFF>
+template <int OFF, bool FIRST = false>      // FIRST: the tile's first k-tile starts the sums (C operand = the literal 0: no accumulator clearing)
 __device__ __forceinline__ void gemm_compute_tile_dma(unsigned aX0, unsigned aX1, unsigned aW0, unsigned aW1, v16i (&acc)[2][2]) {
   // a*: LDS byte addresses of this lane's fragment rows at k-step 0; k-step 1 is the same address with bit 5 flipped (chunk ^ 2)
   v4i x0a, x1a, w0a, w1a, x0b, x1b, w0b, w1b;
@@ -807,10 +807,10 @@ __device__ __forceinline__ void gemm_compute_tile_dma(unsigned aX0, unsigned aX1
       : "=&v"(w0a), "=&v"(w1a), "=&v"(x0a), "=&v"(x1a), "=&v"(w0b), "=&v"(w1b), "=&v"(x0b), "=&v"(x1b)
       : "v"(aW0), "v"(aW1), "v"(aX0), "v"(aX1), "v"(bW0), "v"(bW1), "v"(bX0), "v"(bX1), "i"(OFF)
       : "memory");
-  acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0a, x0a, acc[0][0], 0, 0, 0);
-  acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0a, x1a, acc[0][1], 0, 0, 0);
-  acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1a, x0a, acc[1][0], 0, 0, 0);
-  acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1a, x1a, acc[1][1], 0, 0, 0);
+  acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0a, x0a, FIRST ? (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[0][0], 0, 0, 0);
+  acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0a, x1a, FIRST ? (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[0][1], 0, 0, 0);
+  acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1a, x0a, FIRST ? (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[1][0], 0, 0, 0);
+  acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1a, x1a, FIRST ? (v16i){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[1][1], 0, 0, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0b), "+v"(w1b), "+v"(x0b), "+v"(x1b));   // the k-step-1 fragments are ordered behind this wait
   acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0b, x0b, acc[0][0], 0, 0, 0);
   acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0b, x1b, acc[0][1], 0, 0, 0);
@@ -921,13 +921,7 @@ __global__ __launch_bounds__(128 * MT, MT == 4 ? 4 : (NST == 2 ? 4 : 3)) void k_
     load_resid(1);
   }
 
-  v16i acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+  v16i acc[2][2];                                        // started by the first k-tile
 
   const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int8_t*)lds;
   const unsigned aX0 = lbase + lds_off64(wm * 64 + l31, h), aX1 = lbase + lds_off64(wm * 64 + 32 + l31, h);
@@ -937,7 +931,8 @@ __global__ __launch_bounds__(128 * MT, MT == 4 ? 4 : (NST == 2 ? 4 : 3)) void k_
   GD_STAMP(1);
 
   // one k-tile: own pieces landed (younger requests stay in flight) -> barrier -> refill the freed stage -> MFMAs
-#define P2V_KTILE(S, KT)                                                                                             \
+#define P2V_KTILE(S, KT) P2V_KTILE_(S, KT, false)
+#define P2V_KTILE_(S, KT, FIRST)                                                                                             \
   do {                                                                                                               \
     if (NST == 3) {                                                                                                  \
       /* in flight behind tile KT: tile KT+1 (PCS requests of this wave) */                                          \
@@ -945,32 +940,39 @@ __global__ __launch_bounds__(128 * MT, MT == 4 ? 4 : (NST == 2 ? 4 : 3)) void k_
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
       asm volatile("s_barrier" ::: "memory");    /* tile KT landed for everyone; everyone is done reading tile KT-1 */ \
       if ((KT) + 2 < nk) dma(((S) + 2) % 3, (KT) + 2);                                                               \
-      if (W4) gemm_compute_tile_dma_w4<(S) * STAGE>(aX0, aX1, aW0, aW1, acc);                                        \
-      else gemm_compute_tile_dma<(S) * STAGE>(aX0, aX1, aW0, aW1, acc);                                              \
+      if (W4) gemm_compute_tile_dma_w4<(S) * STAGE, FIRST>(aX0, aX1, aW0, aW1, acc);                                        \
+      else gemm_compute_tile_dma<(S) * STAGE, FIRST>(aX0, aX1, aW0, aW1, acc);                                              \
     } else {                                                                                                         \
       if ((KT) + 1 < nk) { if (PCS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } \
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
       asm volatile("s_barrier" ::: "memory");                                                                        \
-      if (W4) gemm_compute_tile_dma_w4<(S) * STAGE>(aX0, aX1, aW0, aW1, acc);                                        \
-      else gemm_compute_tile_dma<(S) * STAGE>(aX0, aX1, aW0, aW1, acc);                                              \
+      if (W4) gemm_compute_tile_dma_w4<(S) * STAGE, FIRST>(aX0, aX1, aW0, aW1, acc);                                        \
+      else gemm_compute_tile_dma<(S) * STAGE, FIRST>(aX0, aX1, aW0, aW1, acc);                                              \
       if ((KT) + 2 < nk) {                                                                                           \
         asm volatile("s_barrier" ::: "memory");                                                                      \
         dma((S), (KT) + 2);                                                                                          \
       }                                                                                                              \
     }                                                                                                                \
   } while (0)
+  // the first k-tile is peeled: its MFMAs start the sums from the literal 0 (64 accumulator registers are never cleared)
   if (NST == 3) {
-    for (int kt = 0; kt < nk; kt += 3) {
+    P2V_KTILE_(0, 0, true);
+    if (1 < nk) P2V_KTILE(1, 1);
+    if (2 < nk) P2V_KTILE(2, 2);
+    for (int kt = 3; kt < nk; kt += 3) {
       P2V_KTILE(0, kt);
       if (kt + 1 < nk) P2V_KTILE(1, kt + 1);
       if (kt + 2 < nk) P2V_KTILE(2, kt + 2);
     }
   } else {
-    for (int kt = 0; kt < nk; kt += 2) {
+    P2V_KTILE_(0, 0, true);
+    if (1 < nk) P2V_KTILE(1, 1);
+    for (int kt = 2; kt < nk; kt += 2) {
       P2V_KTILE(0, kt);
       if (kt + 1 < nk) P2V_KTILE(1, kt + 1);
     }
   }
+#undef P2V_KTILE_
 #undef P2V_KTILE
 #ifdef P2V_DIAG
   asm volatile("s_nop 0" :: "v"(acc[1][1][0]));
