@@ -78,6 +78,14 @@ struct p2v_plan {
   p2v_ln final_ln;
   float head_inv_s, head_s;
   bool head_set;
+  // LayerNorm constants folded at plan creation (LnPre): [block][6] in the order ln1[0], ln1[1], ln2[0][0], ln2[0][1], ln2[1][0], ln2[1][1];
+  // the arrays live in one device buffer per block, owned by the plan
+  std::vector<LnPre> ln_pre;
+  std::vector<float*> ln_pre_buf;
+  ~p2v_plan() {
+    for (float* b : ln_pre_buf)
+      if (b) (void)hipFree(b);
+  }
 };
 
 static int bit_index(int bits) { return bits == 4 ? 0 : (bits == 8 ? 1 : -1); }
@@ -158,6 +166,8 @@ int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
   }
   p->blocks.resize(d.depth);
   p->block_set.assign(d.depth, 0);
+  p->ln_pre.assign((size_t)d.depth * 6, LnPre{nullptr, nullptr, 0.f, 0.f, 0.f, 0, 0});
+  p->ln_pre_buf.assign(d.depth, nullptr);
   p->embed_set = p->head_set = false;
   p->cls_codes = nullptr;
   *out = p;
@@ -188,6 +198,50 @@ int p2v_plan_set_embed(p2v_plan* plan, float inv_s_input, const p2v_epilogue* e,
   return P2V_OK;
 }
 
+// The fold of ln_prepare (p2vit_kernels.hip), once per plan instead of once per workgroup: the same fp32 products and the same tests on the
+// host (this file is compiled without contraction too), the results uploaded next to the caller's arrays.
+static void fold_ln_constants(p2v_plan* plan, int block) {
+  const int C = plan->d.embed_dim, Cp = round_up(C, 128);
+  if (hipDeviceSynchronize() != hipSuccess) return;          // the caller's uploads may still be in flight on another stream
+  float* dev = plan->ln_pre_buf[block];
+  if (!dev && hipMalloc(&dev, (size_t)12 * Cp * sizeof(float)) != hipSuccess) return;
+  plan->ln_pre_buf[block] = dev;
+  std::vector<float> g(C), b(C), io(C), pm(C), host((size_t)12 * Cp, 0.f);
+  const p2v_block& blk = plan->blocks[block];
+  bool ok = true;
+  LnPre pre[6];
+  for (int i = 0; i < 6 && ok; ++i) {
+    const p2v_ln& l = i < 2 ? blk.ln1[i] : blk.ln2[(i - 2) >> 1][(i - 2) & 1];
+    ok = hipMemcpy(g.data(), l.gamma, C * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(b.data(), l.beta, C * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(io.data(), l.inv_out, C * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(pm.data(), l.post_mul, C * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) break;
+    float* go = host.data() + (size_t)(2 * i) * Cp;
+    float* bo = go + Cp;
+    int pot = 1, pm1 = 1;
+    float gmin = 3.0e38f, gmax = 0.f, bmax = 0.f;
+    for (int c = 0; c < C; ++c) {
+      unsigned ib;
+      memcpy(&ib, &io[c], 4);
+      const int p2 = (int)((ib & 0x807FFFFFu) == 0u) & (int)((ib >> 23) - 32u <= 190u);    // +2^e, far from under/overflow
+      go[c] = g[c] * io[c];
+      bo[c] = b[c] * io[c];
+      const float ga = fabsf(go[c]), ba = fabsf(bo[c]);
+      const int gok = (int)(g[c] == 0.f) | ((int)(ga >= 1.0e-30f) & (int)(ga <= 1.0e30f));
+      const int bok = (int)(b[c] == 0.f) | ((int)(ba >= 1.0e-30f) & (int)(ba <= 1.0e30f));
+      pot &= p2 & gok & bok;
+      pm1 &= (int)(pm[c] == 1.f);
+      gmin = fminf(gmin, ga);
+      gmax = fmaxf(gmax, ga);
+      bmax = fmaxf(bmax, ba);
+    }
+    pre[i] = LnPre{dev + (size_t)(2 * i) * Cp, dev + (size_t)(2 * i + 1) * Cp, gmin, gmax, bmax, pot, pm1};
+  }
+  if (ok) ok = hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+  for (int i = 0; i < 6; ++i) plan->ln_pre[(size_t)block * 6 + i] = ok ? pre[i] : LnPre{nullptr, nullptr, 0.f, 0.f, 0.f, 0, 0};
+}
+
 int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk) {
   if (!plan || !blk) return fail(P2V_E_ARG, "p2v_plan_set_block: null argument");
   if (block < 0 || block >= plan->d.depth) return fail(P2V_E_ARG, "block %d out of range", block);
@@ -207,6 +261,7 @@ int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk) {
   if (rc != P2V_OK) return rc;
   plan->blocks[block] = *blk;
   plan->block_set[block] = 1;
+  fold_ln_constants(plan, block);          // best effort: without it the kernels fold per workgroup, as for the per-operator calls
   return P2V_OK;
 }
 
@@ -355,6 +410,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     const int bq = bit_index(bc[0]), bp = bit_index(bc[1]), b1 = bit_index(bc[2]), b2 = bit_index(bc[3]);
     // norm1 -> /channel_scale -> qact0                                     vit_fquant.py:431-434,284-289
     LnArgs ln{bufX, D, M, D, b.ln1[bq], bufLN, D};
+    ln.pre = p->ln_pre[(size_t)i * 6 + bq];
     // qkv -> qact1                                                          vit_fquant.py:293,307
     p2v_epilogue e{};
     e.inv_s_out = b.inv_s_qkv[bq];
@@ -375,6 +431,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     STEP(P2V_K_GEMM_PROJ, run_gemm(P2V_EPI_RESID, bufATT, D, M, D, D, p->lin[bp][2 + 4 * i], ep, bufX, D, nullptr, st));
     // norm2 (attention's channel scale!) -> /mlp.channel_scale -> mlp.qact0 vit_fquant.py:464, layers_quant.py:305-311
     LnArgs ln2{bufX, D, M, D, b.ln2[bq][b1], bufLN, D};
+    ln2.pre = p->ln_pre[(size_t)i * 6 + 2 + 2 * bq + b1];
     // fc1 -> GELU -> qact1                                                  layers_quant.py:316,331-333
     p2v_epilogue e1{};
     e1.inv_s_out = b.inv_s_fc1;

@@ -25,6 +25,16 @@ struct GemmArgs {
 #endif
 };
 
+// LayerNorm constants folded once, when a plan is created (p2v_plan_set_block), instead of by every workgroup (ln_prepare): gamma / out_scale
+// and beta / out_scale padded with zeros to a multiple of 128 channels, their extreme magnitudes and the two tests of the fast chain.
+// gm == nullptr: the kernel folds them itself (per-operator entry points, Swin op lists).
+struct LnPre {
+  const float* gm;
+  const float* bt;
+  float gmin, gmax, bmax;
+  int pot, pm_one;
+};
+
 struct LnArgs {
   const int8_t* x;
   long long row_stride;
@@ -35,6 +45,7 @@ struct LnArgs {
   long long out_stride;
   int rows_per_half;    // filled by the launcher: consecutive rows per 32-lane half wave
   int force_generic;    // filled by the launcher (P2V_LN_GENERIC=1: A/B and parity runs of the generic chain)
+  LnPre pre;            // optional, see above
 };
 
 struct AttnArgs {

@@ -1694,8 +1694,28 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
     float* sP = sB + NCH * 128;
     int* sM = reinterpret_cast<int*>(sP + NCH * 128);
     LnLane<NCH> L;
-    ln_prepare<NCH, 32>(a.ln, C, a.force_generic != 0, sG, sB, sP, sM, tid, NT, L);
-    __syncthreads();        // every lane holds its folded constants in registers: the scratch (= the panel) may be overwritten
+    if (a.pre.gm) {         // folded when the plan was created (LnPre): straight into registers - no scratch, no barriers
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (l31 + 32 * i) * 4;
+        L.on[i] = c < C;
+        L.gm[i] = *reinterpret_cast<const float4*>(a.pre.gm + c);
+        L.bt[i] = *reinterpret_cast<const float4*>(a.pre.bt + c);
+        L.pm[i] = L.on[i] ? *reinterpret_cast<const float4*>(a.ln.post_mul + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        L.mkf[i] = L.on[i] ? *reinterpret_cast<const float4*>(a.ln.mask + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      L.gmin = a.pre.gmin;
+      L.gmax = a.pre.gmax;
+      L.bmax = a.pre.bmax;
+      L.pot = a.pre.pot != 0 && a.force_generic == 0;
+      L.pm_one = a.pre.pm_one != 0;
+#ifdef P2V_EXP_NOTRIM
+      L.pm_one = false;
+#endif
+    } else {
+      ln_prepare<NCH, 32>(a.ln, C, a.force_generic != 0, sG, sB, sP, sM, tid, NT, L);
+      __syncthreads();      // every lane holds its folded constants in registers: the scratch (= the panel) may be overwritten
+    }
 #pragma unroll 1
     for (int r = 0; r < RPH; r += LR) {
       unsigned wnext[LR][NCH];
