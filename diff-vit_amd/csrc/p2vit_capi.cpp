@@ -201,7 +201,7 @@ int p2v_plan_set_embed(p2v_plan* plan, float inv_s_input, const p2v_epilogue* e,
 // The fold of ln_prepare (p2vit_kernels.hip), once per plan instead of once per workgroup: the same fp32 products and the same tests on the
 // host (this file is compiled without contraction too), the results uploaded next to the caller's arrays.
 static void fold_ln_constants(p2v_plan* plan, int block) {
-  const int C = plan->d.embed_dim, Cp = round_up(C, 128);
+  const int C = plan->d.embed_dim, Cp = round_up(C, 256);      // (a row group of 64 lanes covers 256 channels per chunk)
   if (hipDeviceSynchronize() != hipSuccess) return;          // the caller's uploads may still be in flight on another stream
   float* dev = plan->ln_pre_buf[block];
   if (!dev && hipMalloc(&dev, (size_t)12 * Cp * sizeof(float)) != hipSuccess) return;

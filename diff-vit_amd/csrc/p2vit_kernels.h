@@ -26,7 +26,7 @@ struct GemmArgs {
 };
 
 // LayerNorm constants folded once, when a plan is created (p2v_plan_set_block), instead of by every workgroup (ln_prepare): gamma / out_scale
-// and beta / out_scale padded with zeros to a multiple of 128 channels, their extreme magnitudes and the two tests of the fast chain.
+// and beta / out_scale padded with zeros to a multiple of 256 channels, their extreme magnitudes and the two tests of the fast chain.
 // gm == nullptr: the kernel folds them itself (per-operator entry points, Swin op lists).
 struct LnPre {
   const float* gm;

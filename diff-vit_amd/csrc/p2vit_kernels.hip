@@ -1330,7 +1330,7 @@ __device__ __forceinline__ void ln_rows(const unsigned (&wcur)[R][NCH], const LL
 #ifndef LN_LDSC
 #define LN_LDSC true
 #endif
-template <int NCH, int LANES>
+template <int NCH, int LANES, bool PRE>        // PRE: the constants were folded when the plan was created (LnPre)
 __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
   // per-channel constants are folded once per workgroup, shared through LDS, then held in registers (re-reading them from
   // LDS per row frees 46 VGPRs but measured 10 % slower: the kernel is bound by VALU issue, not by occupancy)
@@ -1338,7 +1338,43 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
   __shared__ __attribute__((aligned(16))) int sM[NCH * LANES * 4];
   const int tid = threadIdx.x, l32 = tid & (LANES - 1), hw = tid / LANES;   // l32: lane within the row group
   LnLane<NCH, LN_LDSC> L;
-  ln_prepare<NCH, LANES>(a.ln, a.C, a.force_generic != 0, sG, sB, sP, sM, tid, 256, L);
+  if constexpr (PRE) {      // only post_mul and the mask go through LDS (LN_LDSC), one barrier
+    for (int t4 = tid; t4 < NCH * LANES; t4 += 256) {
+      const int c = t4 * 4;
+      float4 pmv = make_float4(0.f, 0.f, 0.f, 0.f), mk = pmv;
+      if (c < a.C) {
+        pmv = *reinterpret_cast<const float4*>(a.ln.post_mul + c);
+        mk = *reinterpret_cast<const float4*>(a.ln.mask + c);
+      }
+      *reinterpret_cast<float4*>(sP + c) = pmv;
+      *reinterpret_cast<float4*>(sM + c) = mk;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (l32 + LANES * i) * 4;
+      L.on[i] = c < a.C;
+      L.gm[i] = *reinterpret_cast<const float4*>(a.pre.gm + c);
+      L.bt[i] = *reinterpret_cast<const float4*>(a.pre.bt + c);
+      if constexpr (sizeof(L.pm) == sizeof(float4) * NCH) {
+        L.pm[i] = *reinterpret_cast<const float4*>(sP + c);
+        L.mkf[i] = *reinterpret_cast<const float4*>(sM + c);
+      }
+    }
+    L.sPl = sP + l32 * 4;
+    L.sMl = reinterpret_cast<const float*>(sM) + l32 * 4;
+    L.cstride = LANES * 4;
+    L.gmin = a.pre.gmin;
+    L.gmax = a.pre.gmax;
+    L.bmax = a.pre.bmax;
+    L.pot = a.pre.pot != 0 && a.force_generic == 0;
+    L.pm_one = a.pre.pm_one != 0;
+#ifdef P2V_EXP_NOTRIM
+    L.pm_one = false;
+#endif
+  } else {
+    ln_prepare<NCH, LANES>(a.ln, a.C, a.force_generic != 0, sG, sB, sP, sM, tid, 256, L);
+  }
   const int LN_ROWS = a.rows_per_half;
   const long long row0 = ((long long)blockIdx.x * (256 / LANES) + hw) * LN_ROWS;
   // Row r+1 is requested at the top of the iteration of row r and first touched just before the stores of row r.  The two
@@ -2786,20 +2822,20 @@ int p2v_launch_layernorm(const LnArgs& a_, hipStream_t st) {
   dim3 grid((unsigned)((a.rows + rows_per_block - 1) / rows_per_block)), block(256);
   if (wide) {
     switch (nch) {
-      case 2: hipLaunchKernelGGL((k_int_layernorm<2, 64>), grid, block, 0, st, a); break;
-      case 3: hipLaunchKernelGGL((k_int_layernorm<3, 64>), grid, block, 0, st, a); break;
-      case 4: hipLaunchKernelGGL((k_int_layernorm<4, 64>), grid, block, 0, st, a); break;
-      case 5: hipLaunchKernelGGL((k_int_layernorm<5, 64>), grid, block, 0, st, a); break;
-      case 6: hipLaunchKernelGGL((k_int_layernorm<6, 64>), grid, block, 0, st, a); break;
-      case 7: hipLaunchKernelGGL((k_int_layernorm<7, 64>), grid, block, 0, st, a); break;
-      case 8: hipLaunchKernelGGL((k_int_layernorm<8, 64>), grid, block, 0, st, a); break;
+      case 2: if (a.pre.gm) hipLaunchKernelGGL((k_int_layernorm<2, 64, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((k_int_layernorm<2, 64, false>), grid, block, 0, st, a); break;
+      case 3: if (a.pre.gm) hipLaunchKernelGGL((k_int_layernorm<3, 64, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((k_int_layernorm<3, 64, false>), grid, block, 0, st, a); break;
+      case 4: if (a.pre.gm) hipLaunchKernelGGL((k_int_layernorm<4, 64, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((k_int_layernorm<4, 64, false>), grid, block, 0, st, a); break;
+      case 5: if (a.pre.gm) hipLaunchKernelGGL((k_int_layernorm<5, 64, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((k_int_layernorm<5, 64, false>), grid, block, 0, st, a); break;
+      case 6: if (a.pre.gm) hipLaunchKernelGGL((k_int_layernorm<6, 64, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((k_int_layernorm<6, 64, false>), grid, block, 0, st, a); break;
+      case 7: if (a.pre.gm) hipLaunchKernelGGL((k_int_layernorm<7, 64, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((k_int_layernorm<7, 64, false>), grid, block, 0, st, a); break;
+      case 8: if (a.pre.gm) hipLaunchKernelGGL((k_int_layernorm<8, 64, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((k_int_layernorm<8, 64, false>), grid, block, 0, st, a); break;
       default: return -1;
     }
   } else {
     switch (nch) {
-      case 1: hipLaunchKernelGGL((k_int_layernorm<1, 32>), grid, block, 0, st, a); break;
-      case 2: hipLaunchKernelGGL((k_int_layernorm<2, 32>), grid, block, 0, st, a); break;
-      case 3: hipLaunchKernelGGL((k_int_layernorm<3, 32>), grid, block, 0, st, a); break;
+      case 1: if (a.pre.gm) hipLaunchKernelGGL((k_int_layernorm<1, 32, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((k_int_layernorm<1, 32, false>), grid, block, 0, st, a); break;
+      case 2: if (a.pre.gm) hipLaunchKernelGGL((k_int_layernorm<2, 32, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((k_int_layernorm<2, 32, false>), grid, block, 0, st, a); break;
+      case 3: if (a.pre.gm) hipLaunchKernelGGL((k_int_layernorm<3, 32, true>), grid, block, 0, st, a); else hipLaunchKernelGGL((k_int_layernorm<3, 32, false>), grid, block, 0, st, a); break;
       default: return -1;
     }
   }
