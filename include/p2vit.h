@@ -182,6 +182,10 @@ typedef struct p2v_block {
   p2v_gelu_tab gelu_fc1;    /* threshold table of fc1 -> GELU -> qact1 for inv_s_fc1 (table may be NULL) */
   p2v_epilogue fc2_epi;     /* RESID */
 } p2v_block;
+/* Stores the block's constants (the arrays stay the caller's and must outlive the plan) and - since round 3 - reads the LayerNorm arrays
+ * back once to fold gamma / out_scale and beta / out_scale and to run the fast-chain tests on the host, so that the kernels of p2v_forward
+ * do not repeat that per workgroup.  The call therefore synchronises the device (hipDeviceSynchronize) and must come after the arrays have
+ * been written; changing an array afterwards requires setting the block again.  The folded copies are owned by the plan. */
 int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk);
 
 int p2v_plan_set_head(p2v_plan* plan, const p2v_ln* final_ln, float inv_s_out, float s_out);
