@@ -114,7 +114,8 @@ def bench_swin(args, dva, dev, world, rank):
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8' if args.bits == 8 else 'int4w/int8a', 'data': 'synthetic',
             'config': {'workload': '%s PoT-PTQ forward, int%d weights, %dx%d, batch %d per GPU' % (args.model, args.bits, arch['img_size'], arch['img_size'], B),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'streams_per_gpu': args.streams,
-                       'collective': 'all_gather(logits)' if dist is not None else 'none', 'backend': args.backend if dist is not None else None},
+                       'collective': 'all_gather(logits)' if dist is not None else 'none', 'backend': args.backend if dist is not None else None,
+                       **args.identity},
             'roofline': roof,
             'top1_agreement_fp32': round(float((out[0][:base.shape[0]].argmax(1).cpu() == fp32_top1).float().mean()), 4),
             'model_mfma_frac': round(model_ops / (el / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
@@ -175,6 +176,8 @@ def main():
     ap.add_argument('--model', default=MODEL, choices=('deit_tiny', 'deit_small', 'deit_base', 'vit_base', 'swin_tiny', 'swin_base'))
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for a rehearsal on one GPU)')
     ap.add_argument('--slices', default=None, help='explicit batch slices, e.g. 83,83,83,7 (default: FrozenPlan.slice_sizes)')
+    ap.add_argument('--share-device', action='store_true', help='REHEARSAL ONLY: allow more ranks than visible GPUs (ranks then share devices; the line '
+                    'says so in config.devices / distinct_devices).  Without it such a launch exits non-zero instead of printing an "N-GPU" number')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the all-gather of the logits even at '
                     'world size 1 (under torch.distributed.run --nproc-per-node 1): exercises the RCCL branch on a one-GPU box')
     args = ap.parse_args()
@@ -188,9 +191,14 @@ def main():
         sys.exit('bench.py --gpus %d was started with WORLD_SIZE=%d' % (args.gpus, world))
     if world > 1:      # the one-off host calibration of every rank runs at the same time: share the host cores instead of oversubscribing them
         torch.set_num_threads(max(1, min(32, (os.cpu_count() or 8) // world)))
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and not args.share_device:
+        sys.exit('bench.py: %d ranks but %d visible GPU(s): refusing to stack ranks on one device (an "%d-GPU" number would be a lie). '
+                 'Pass --share-device for a rehearsal on fewer GPUs.' % (world, n_dev, world))
+    hipq_before = torch.cuda.is_initialized()            # HIP initialised before the package could set GPU_MAX_HW_QUEUES?
     import diff_vit_amd as dva
     from diff_vit_amd import calib_io
-    local = local % max(1, torch.cuda.device_count())
+    local = local % max(1, n_dev)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
@@ -205,6 +213,26 @@ def main():
             os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
         dist.init_process_group(args.backend, **({'device_id': dev} if args.backend == 'nccl' else {}))
     args.dist = dist
+    # who is really here: every rank reports its device; rank 0 prints what the GROUP saw, not what the launcher was asked for
+    props = torch.cuda.get_device_properties(dev)
+    me = {'rank': rank, 'local_device': local, 'name': props.name, 'uuid': str(getattr(props, 'uuid', '')),
+          'pci_bus_id': '%04x:%02x:%02x' % (getattr(props, 'pci_domain_id', 0), getattr(props, 'pci_bus_id', 0), getattr(props, 'pci_device_id', 0)),
+          'host': os.uname().nodename}
+    ident = [me]
+    if dist is not None:
+        ident = [None] * dist.get_world_size()
+        dist.all_gather_object(ident, me)
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    if ranks_seen != world:
+        sys.exit('bench.py: WORLD_SIZE=%d but the process group has %d ranks' % (world, ranks_seen))
+    distinct = len({(d['host'], d['uuid'] or d['pci_bus_id'], d['local_device'] if not d['uuid'] else 0) for d in ident})
+    if distinct < ranks_seen and not args.share_device:
+        sys.exit('bench.py: %d ranks on %d distinct devices (%s): not an %d-GPU run' % (ranks_seen, distinct, ident, ranks_seen))
+    args.identity = {'ranks_seen': ranks_seen, 'distinct_devices': distinct,
+                     'devices': ['%d:%s/%s' % (d['rank'], d['pci_bus_id'], d['name']) for d in ident],
+                     'shared_device_rehearsal': bool(distinct < ranks_seen),
+                     'gpu_max_hw_queues': dict(dva.HW_QUEUES, hip_initialised_before_import=bool(hipq_before))}
+    world = ranks_seen
 
     if args.model.startswith('swin'):
         return bench_swin(args, dva, dev, world, rank)
@@ -272,34 +300,67 @@ def main():
     top1_fp32 = float((logits[:base.shape[0]].argmax(1).cpu() == fp32_top1).float().mean())   # BASELINE metric: top-1 vs fp32
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, measured live ----------------------
-    # One LAUNCH in the timed region covers one batch slice (B / streams images, forward_streams): the profile pass times
-    # exactly those launches - same kernels, same shapes - with events recorded on the launch stream between consecutive
-    # launches, so its average agrees with the rocprofv3 --kernel-trace average of this command (profiles/).
+    # One LAUNCH in the timed region covers one batch slice (B / streams images, forward_streams): the profile passes time exactly those
+    # launches - same kernels, same shapes - with events recorded on the launch stream between consecutive launches (the events are created
+    # before the first launch is enqueued, p2v_forward_profile), (a) one slice alone = `isolated`, what rocprofv3 --kernel-trace of a
+    # one-stream run shows, and (b) all slices concurrently = `under_overlap`, the regime of the headline.  Per kind: mean, median, min, max
+    # over all launches of five passes.  The DOMINANT kernel is the kind with the largest share of the step under overlap.
+    def stats(v):
+        v = sorted(v)
+        return {'mean': sum(v) / len(v), 'median': v[len(v) // 2], 'min': v[0], 'max': v[-1]}
+
     n_sl = len(slices)
     Bl = max(slices)
-    prof = {}
-    for _ in range(5):
-        for kind, ms in plan.profile(x[:Bl], bits):
+    prof, last_pass = {}, []
+    n_pass = 5
+    for _ in range(n_pass):
+        last_pass = plan.profile(x[:Bl], bits)
+        for kind, ms in last_pass:
             prof.setdefault(kind, []).append(ms)
-    tot = {k: n_sl * sum(v) / 5 for k, v in prof.items()}        # per step: every slice issues the same launches (a smaller last slice is charged like a full one)
-    dom = max(tot, key=tot.get)
-    avg_ms = sum(prof[dom]) / len(prof[dom])
+    iso = {k: stats(v) for k, v in prof.items()}
+    launches = {k: len(v) // n_pass for k, v in prof.items()}                  # per slice and step
+    tot = {k: n_sl * iso[k]['median'] * launches[k] for k in prof}             # per step: every slice issues the same launches
+    ovl, ovl_wall = {}, None
+    if n_sl > 1:
+        acc_o, walls = {}, []
+        for _ in range(3):
+            per, wall = plan.profile_streams(x, bits, args.streams, slices, rounds=3)
+            walls.append(wall)
+            for pslice in per:
+                for kind, ms in pslice:
+                    acc_o.setdefault(kind, []).append(ms)
+        ovl = {k: stats(v) for k, v in acc_o.items()}
+        ovl_wall = round(sorted(walls)[1], 3)
+    tot_ovl = {k: ovl[k]['median'] * launches[k] for k in ovl} if ovl else tot
+    dom = max(tot_ovl, key=tot_ovl.get)
     ops, byts = algorithmic_work(dom, arch, Bl, args.bits)
+    avg_ms = iso[dom]['mean']
     if ops > 0:
         ach = ops / (avg_ms * 1e-3) / 1e12
         roof = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=PEAK_INT8_TOPS, unit='TFLOP/s',
                     frac=round(ach / PEAK_INT8_TOPS, 4))
+        if ovl:
+            roof['frac_under_overlap'] = round(ops / (ovl[dom]['mean'] * 1e-3) / 1e12 / PEAK_INT8_TOPS, 4)
     else:
         ach = byts / (avg_ms * 1e-3) / 1e9
         roof = dict(kernel=dom, bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                     frac=round(ach / PEAK_HBM_GBS, 4))
+        if ovl:
+            roof['frac_under_overlap'] = round(byts / (ovl[dom]['mean'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+    roof['dominant_by'] = 'share of the step under overlap' if ovl else 'share of the isolated slice'
     # what the matrix pipe sustains on real data under the board's power limit (tools/ubench/mfma_power.hip, profiles/r03_mfma_power.txt):
     # the guide's peak is reached only with constant operands; listed beside it, never used for `frac`
     if roof['bound'] == 'mfma':
         roof['peak_sustained_measured'] = {'random_operands_in_registers': 3400.0, 'operands_from_lds': 2630.0, 'unit': 'TFLOP/s',
                                            'source': 'profiles/r03_mfma_power.txt (power-limited clock 1.66 / 1.41 GHz)'}
+    us = lambda st: {k: round(v * 1e3, 2) for k, v in st.items()}
     roof['avg_launch_us'] = round(avg_ms * 1e3, 2)
-    roof['launches_per_step'] = n_sl * (len(prof[dom]) // 5)
+    roof['launch_us'] = us(iso[dom])
+    roof['launch_us_under_overlap'] = us(ovl[dom]) if ovl else None
+    # the launches of the dominant kind and of the fused LayerNorm+qkv kernel in program order (one per block) in the last isolated pass:
+    # shows whether a deviation sits on one launch (e.g. block 0, right behind the stem) or on all of them
+    roof['launch_us_by_block'] = {k: [round(ms * 1e3, 2) for kind, ms in last_pass if kind == k] for k in sorted({dom, 'ln_gemm_qkv'} & set(prof))}
+    roof['launches_per_step'] = n_sl * launches[dom]
     roof['images_per_launch'] = Bl
     roof['algorithmic_per_launch'] = {'ops': ops, 'bytes': byts}
     # HBM-side bytes of that launch: PMC counters cannot be read inside the run (rocprofv3 wraps the process), so the figure is the
@@ -314,22 +375,7 @@ def main():
         except Exception:
             pass
     breakdown = {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
-    # the same launches WHILE the other slices' kernels run (the regime the headline is measured in): HIP events on every slice's
-    # stream, three steps back to back, the middle one reported (FrozenPlan.profile_streams; the events cost ~3 us per launch)
-    ovl, ovl_wall = {}, None
-    if n_sl > 1:
-        acc_o = {}
-        walls = []
-        for _ in range(3):
-            per, wall = plan.profile_streams(x, bits, args.streams, slices, rounds=3)
-            walls.append(wall)
-            for pslice in per:
-                for kind, ms in pslice:
-                    acc_o.setdefault(kind, []).append(ms)
-        ovl = {k: round(sum(v) / len(v) * 1e3, 2) for k, v in acc_o.items()}
-        ovl_wall = round(sorted(walls)[1], 3)
-    iso_us = {k: round(sum(v) / len(v) * 1e3, 2) for k, v in prof.items()}
-    model_ops = sum(algorithmic_work(k, arch, Bl, args.bits)[0] * n_sl * (len(v) // 5) for k, v in prof.items())
+    model_ops = sum(algorithmic_work(k, arch, Bl, args.bits)[0] * n_sl * launches[k] for k in prof)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -389,14 +435,16 @@ def main():
             'config': {'workload': args.model + ' PoT-PTQ forward, bit_config=[%d]*50, 224x224, batch %d per GPU' % (args.bits, B),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'streams_per_gpu': args.streams, 'batch_slices': slices,
                        'collective': 'all_gather(logits)' if dist is not None else 'none', 'backend': args.backend if dist is not None else None,
-                       'gathered_logits_equal_per_rank_forwards': gather_ok},
+                       'gathered_logits_equal_per_rank_forwards': gather_ok, **args.identity},
             'roofline': roof,
             'top1_agreement_fp32': round(top1_fp32, 4),
             'model_mfma_frac': round(model_ops / (el / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
             'kernel_ms_per_step': breakdown,
-            'kernel_us_per_launch': {k: {'isolated': iso_us[k], 'under_overlap': ovl.get(k)} for k in sorted(iso_us, key=lambda k: -tot[k])},
-            'overlap': {'longest_stream_ms_with_events': ovl_wall, 'note': 'under_overlap = launch duration while the other slices run (HIP events on each '
-                        'stream, FrozenPlan.profile_streams); isolated = one slice alone'} if ovl else None,
+            'kernel_us_per_launch': {k: {'isolated': round(iso[k]['median'] * 1e3, 2), 'under_overlap': round(ovl[k]['median'] * 1e3, 2) if k in ovl else None,
+                                         'share_under_overlap': round(tot_ovl[k] / sum(tot_ovl.values()), 3) if k in tot_ovl else None}
+                                     for k in sorted(iso, key=lambda k: -tot_ovl.get(k, 0.0))},
+            'overlap': {'longest_stream_ms_with_events': ovl_wall, 'note': 'medians over all launches; under_overlap = launch duration while the other slices '
+                        'run (HIP events on each stream, FrozenPlan.profile_streams); isolated = one slice alone'} if ovl else None,
             'cpu_baseline': cpu,
             'calibration': {'seconds': round(t_cal, 2), 'device': 'host cpu (float pass + observer searches; harness.calibrate_model where=host)', 'tensors': len(ref_calib), 'tensors_bit_equal_reference': n_equal,
                             'scale_elements': n_elems, 'elements_off_by_a_power_of_two': exp_flips},

@@ -7,7 +7,27 @@ import os as _os
 # hardware queues is used up as soon as RCCL (torch.distributed "nccl") is initialised in the process - two slice streams then share a
 # queue and every rank's step takes 3.6 instead of 2.64 ms (tools/gather_cost.py).  The HIP runtime reads the variable when it initialises
 # (the first HIP call of the process); an explicit setting of the user wins.
+_hwq_user = 'GPU_MAX_HW_QUEUES' in _os.environ
 _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+
+def _hip_already_up():
+    import sys
+    t = sys.modules.get('torch')
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+# what is in effect, for bench.py's JSON line and for callers that want to check: `in_effect` is False when this import came too late
+HW_QUEUES = {'value': _os.environ['GPU_MAX_HW_QUEUES'], 'set_by': 'environment' if _hwq_user else 'diff_vit_amd default',
+             'in_effect': bool(_hwq_user or not _hip_already_up())}
+if not HW_QUEUES['in_effect']:
+    import warnings as _warnings
+    _warnings.warn('diff_vit_amd: the HIP runtime was initialised before this import and GPU_MAX_HW_QUEUES was not set: the default of 8 '
+                   'hardware queues is NOT in effect; with RCCL initialised the three-stream forward then loses ~28 % '
+                   '(profiles/r03_rccl_queues.txt). Export GPU_MAX_HW_QUEUES=8 before the process makes its first HIP call.', RuntimeWarning)
 
 from . import synth, engine, calib_io, checkpoint, dp, harness, search, ops  # noqa: F401
 from .config import Config  # noqa: F401

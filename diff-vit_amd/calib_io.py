@@ -65,7 +65,8 @@ def save_plan(path, model):
     import json
     import numpy as np
     kind = 'swin' if 'depths' in model.arch else 'vit'
-    out = {'meta': np.array(json.dumps({'kind': kind, 'arch': model.arch, 'in_chans': model.in_chans, 'format': 1}))}
+    out = {'meta': np.array(json.dumps({'kind': kind, 'arch': model.arch, 'in_chans': model.in_chans, 'format': 1,
+                                        'input_quant': bool(getattr(model, 'input_quant', True))}))}
     for k, v in flatten(model.export_calib()).items():
         out['calib/' + k] = v.detach().float().cpu().numpy()
     for k, v in model.state_dict().items():
@@ -91,4 +92,5 @@ def load_plan(path, device='cuda', bits=8):
         calib = {k: (v.reshape(-1) if torch.is_tensor(v) else v) for k, v in calib.items()}
         return SwinPlan(arch, sd, calib, device=device, in_chans=meta['in_chans'], bits=bits)
     from .plan import FrozenPlan
-    return FrozenPlan(arch, sd, calib, device=device, in_chans=meta['in_chans'])
+    # input_quant False = the reference's vit_large factory (vit_fquant.py:925); files written before the key existed are input_quant models
+    return FrozenPlan(arch, sd, calib, device=device, in_chans=meta['in_chans'], input_quant=bool(meta.get('input_quant', True)))

@@ -125,4 +125,31 @@ def load_pretrained(model, factory_name):
         raise FileNotFoundError('pretrained=True: %s is not in the torch-hub cache (the reference would download it; there is no network here). '
                                 'Place the file at %s or load a local checkpoint with checkpoint.load_checkpoint(model, path).'
                                 % (PRETRAINED_FILES[factory_name], path))
-    return load_checkpoint(model, path)
+    _verify_hub_hash(path)
+    res = load_checkpoint(model, path)
+    missing, unexpected = list(getattr(res, 'missing_keys', ())), list(getattr(res, 'unexpected_keys', ()))
+    if missing or unexpected:          # strict=False like the reference, but not silently: a wrong file shows up here
+        import warnings
+        warnings.warn('pretrained=True (%s): %d missing and %d unexpected keys, e.g. %s' % (
+            os.path.basename(path), len(missing), len(unexpected), (missing + unexpected)[:4]))
+    return res
+
+
+def _verify_hub_hash(path):
+    """torch.hub file names end in ``-<first hex digits of the sha256>.<ext>`` and ``load_state_dict_from_url(check_hash=True)`` - what
+    the reference's DeiT factories call (vit_fquant.py:822-828) - refuses a file whose digest does not start with them.  The same test
+    on the cached file, with hashlib (nothing is fetched).  Names without such a suffix (the Swin / Google .npz files) are not checked,
+    as in torch.hub."""
+    import hashlib
+    import os
+    import re
+    m = re.search(r'-([a-f0-9]{8,})\.[A-Za-z0-9]+$', os.path.basename(path))
+    if not m:
+        return
+    h = hashlib.sha256()
+    with open(path, 'rb') as f:
+        for chunk in iter(lambda: f.read(1 << 20), b''):
+            h.update(chunk)
+    if not h.hexdigest().startswith(m.group(1)):
+        raise RuntimeError('invalid hash value (expected "%s", got "%s"): %s is truncated or not the file the reference downloads'
+                           % (m.group(1), h.hexdigest()[:len(m.group(1))], path))

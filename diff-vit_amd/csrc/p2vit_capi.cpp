@@ -3,7 +3,8 @@
 // The plan object is the frozen integer state the reference keeps in Python attributes after
 // model_close_calibrate(); model_quant() (test_quant.py:248-249): quantizer.scale / dic_scale / best_*
 // lists.  p2v_forward walks the graph of VisionTransformer.forward_features/forward
-// (models/vit_fquant.py:700-799) and enqueues 7 kernels per block on the caller's stream.
+// (models/vit_fquant.py:700-799) and enqueues 5 kernels per block on the caller's stream (LayerNorm+qkv, attention, proj+residual,
+// LayerNorm+fc1+GELU, fc2+residual; 7 for models wider than the fused LayerNorm+GEMM kernel covers).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
@@ -82,9 +83,14 @@ struct p2v_plan {
   // the arrays live in one device buffer per block, owned by the plan
   std::vector<LnPre> ln_pre;
   std::vector<float*> ln_pre_buf;
+  std::vector<char> block_folded;
+  int device = -1;                  // the device that owns the folded constants (= the device of the caller's arrays)
   ~p2v_plan() {
+    int prev = -1;
+    const bool sw = device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device && hipSetDevice(device) == hipSuccess;
     for (float* b : ln_pre_buf)
       if (b) (void)hipFree(b);
+    if (sw) (void)hipSetDevice(prev);
   }
 };
 
@@ -95,7 +101,6 @@ extern "C" {
 extern int g_ln_generic;
 extern int g_ln_rows;
 extern int g_attn_waves;
-extern int g_gemm_stages;
 extern int g_ln_gemm;
 extern int g_ln_gemm_ver;
 extern int g_gemm_tile;
@@ -107,8 +112,6 @@ static void read_env_once() {
   done = true;
   const char* e = getenv("P2V_ATTN_WAVES");
   if (e && atoi(e) >= 4 && atoi(e) <= 8) g_attn_waves = atoi(e);
-  e = getenv("P2V_GEMM_STAGES");
-  if (e && (atoi(e) == 2 || atoi(e) == 3)) g_gemm_stages = atoi(e);
   e = getenv("P2V_LN_GEMM");
   if (e) g_ln_gemm = atoi(e) != 0;
   e = getenv("P2V_LN_GEMM_V");
@@ -130,7 +133,6 @@ int p2v_set_tuning(const char* name, int value) {
   if (!strcmp(name, "ln_generic")) { g_ln_generic = value != 0; return P2V_OK; }
   if (!strcmp(name, "ln_rows") && value >= 1 && value <= 64) { g_ln_rows = value; return P2V_OK; }
   if (!strcmp(name, "attn_waves") && value >= 4 && value <= 8) { g_attn_waves = value; return P2V_OK; }
-  if (!strcmp(name, "gemm_stages") && (value == 2 || value == 3)) { g_gemm_stages = value; return P2V_OK; }
   if (!strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) { g_gemm_tile = value; return P2V_OK; }
   return fail(P2V_E_ARG, "p2v_set_tuning: unknown switch or value out of range: %s = %d", name, value);
 }
@@ -168,6 +170,7 @@ int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
   p->block_set.assign(d.depth, 0);
   p->ln_pre.assign((size_t)d.depth * 6, LnPre{nullptr, nullptr, 0.f, 0.f, 0.f, 0, 0});
   p->ln_pre_buf.assign(d.depth, nullptr);
+  p->block_folded.assign(d.depth, 0);
   p->embed_set = p->head_set = false;
   p->cls_codes = nullptr;
   *out = p;
@@ -198,25 +201,51 @@ int p2v_plan_set_embed(p2v_plan* plan, float inv_s_input, const p2v_epilogue* e,
   return P2V_OK;
 }
 
-// The fold of ln_prepare (p2vit_kernels.hip), once per plan instead of once per workgroup: the same fp32 products and the same tests on the
-// host (this file is compiled without contraction too), the results uploaded next to the caller's arrays.
-static void fold_ln_constants(p2v_plan* plan, int block) {
+// The fold of ln_prepare (p2vit_ln.hip), once per plan instead of once per workgroup: the same fp32 products and the same tests on the
+// host (this file is compiled without contraction too), the results uploaded next to the caller's arrays - on the device that OWNS the
+// caller's arrays, whatever the process's current device is (a plan built for cuda:1 while cuda:0 is current).  Returns false, with the
+// reason in p2v_last_error(), when the constants could not be folded: the block's kernels then fold per workgroup, with the same results.
+static bool fold_ln_constants(p2v_plan* plan, int block) {
   const int C = plan->d.embed_dim, Cp = round_up(C, 256);      // (a row group of 64 lanes covers 256 channels per chunk)
-  if (hipDeviceSynchronize() != hipSuccess) return;          // the caller's uploads may still be in flight on another stream
-  float* dev = plan->ln_pre_buf[block];
-  if (!dev && hipMalloc(&dev, (size_t)12 * Cp * sizeof(float)) != hipSuccess) return;
-  plan->ln_pre_buf[block] = dev;
-  std::vector<float> g(C), b(C), io(C), pm(C), host((size_t)12 * Cp, 0.f);
+  // stale state first: a second p2v_plan_set_block on this block must never leave the constants of the previous arrays behind
+  for (int i = 0; i < 6; ++i) plan->ln_pre[(size_t)block * 6 + i] = LnPre{nullptr, nullptr, 0.f, 0.f, 0.f, 0, 0};
   const p2v_block& blk = plan->blocks[block];
-  bool ok = true;
+  int prev = -1, own = -1;
+  hipPointerAttribute_t pa;
+  if (hipGetDevice(&prev) != hipSuccess || hipPointerGetAttributes(&pa, blk.ln1[0].gamma) != hipSuccess) {
+    (void)hipGetLastError();
+    fail(P2V_OK, "p2v_plan_set_block: LayerNorm constants of block %d not folded at plan time (cannot locate the device of gamma)", block);
+    return false;
+  }
+  own = pa.device;
+  if (plan->device >= 0 && plan->device != own) {
+    fail(P2V_OK, "p2v_plan_set_block: block %d lives on device %d, earlier blocks on device %d: not folded at plan time", block, own, plan->device);
+    return false;
+  }
+  struct DeviceGuard {          // set the owning device for the sync / malloc / copies below, restore on every path
+    int prev, own;
+    DeviceGuard(int p, int o) : prev(p), own(o) { if (own != prev) (void)hipSetDevice(own); }
+    ~DeviceGuard() { if (own != prev) (void)hipSetDevice(prev); }
+  } guard(prev, own);
+  hipError_t e = hipDeviceSynchronize();                        // the caller's uploads may still be in flight on another stream
+  float* dev = plan->ln_pre_buf[block];
+  if (e == hipSuccess && !dev) e = hipMalloc(&dev, (size_t)12 * Cp * sizeof(float));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();                                    // do not leave the error for an unrelated CHECK_LAUNCH
+    fail(P2V_OK, "p2v_plan_set_block: LayerNorm constants of block %d not folded at plan time (%s)", block, hipGetErrorString(e));
+    return false;
+  }
+  plan->ln_pre_buf[block] = dev;
+  plan->device = own;
+  std::vector<float> g(C), b(C), io(C), pm(C), host((size_t)12 * Cp, 0.f);
   LnPre pre[6];
-  for (int i = 0; i < 6 && ok; ++i) {
+  for (int i = 0; i < 6 && e == hipSuccess; ++i) {
     const p2v_ln& l = i < 2 ? blk.ln1[i] : blk.ln2[(i - 2) >> 1][(i - 2) & 1];
-    ok = hipMemcpy(g.data(), l.gamma, C * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(b.data(), l.beta, C * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(io.data(), l.inv_out, C * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
-         hipMemcpy(pm.data(), l.post_mul, C * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
-    if (!ok) break;
+    e = hipMemcpy(g.data(), l.gamma, C * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(b.data(), l.beta, C * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(io.data(), l.inv_out, C * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(pm.data(), l.post_mul, C * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) break;
     float* go = host.data() + (size_t)(2 * i) * Cp;
     float* bo = go + Cp;
     int pot = 1, pm1 = 1;
@@ -238,8 +267,14 @@ static void fold_ln_constants(p2v_plan* plan, int block) {
     }
     pre[i] = LnPre{dev + (size_t)(2 * i) * Cp, dev + (size_t)(2 * i + 1) * Cp, gmin, gmax, bmax, pot, pm1};
   }
-  if (ok) ok = hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
-  for (int i = 0; i < 6; ++i) plan->ln_pre[(size_t)block * 6 + i] = ok ? pre[i] : LnPre{nullptr, nullptr, 0.f, 0.f, 0.f, 0, 0};
+  if (e == hipSuccess) e = hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    fail(P2V_OK, "p2v_plan_set_block: LayerNorm constants of block %d not folded at plan time (%s)", block, hipGetErrorString(e));
+    return false;
+  }
+  for (int i = 0; i < 6; ++i) plan->ln_pre[(size_t)block * 6 + i] = pre[i];
+  return true;
 }
 
 int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk) {
@@ -261,8 +296,16 @@ int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk) {
   if (rc != P2V_OK) return rc;
   plan->blocks[block] = *blk;
   plan->block_set[block] = 1;
-  fold_ln_constants(plan, block);          // best effort: without it the kernels fold per workgroup, as for the per-operator calls
+  // without the fold the kernels fold per workgroup, as for the per-operator calls: same results, so the call still succeeds; the reason
+  // is left in p2v_last_error() and p2v_plan_block_prefolded() tells
+  g_err[0] = 0;
+  plan->block_folded[block] = fold_ln_constants(plan, block) ? 1 : 0;
   return P2V_OK;
+}
+
+int p2v_plan_block_prefolded(const p2v_plan* plan, int block) {
+  if (!plan || block < 0 || block >= plan->d.depth) return fail(P2V_E_ARG, "p2v_plan_block_prefolded: bad argument");
+  return plan->block_folded[block] ? 1 : 0;
 }
 
 int p2v_plan_set_head(p2v_plan* plan, const p2v_ln* final_ln, float inv_s_out, float s_out) {
@@ -341,9 +384,19 @@ static int run_ln_gemm(int epi, const LnArgs& a, const p2v_linear& lin, const p2
 }
 
 struct Prof {
-  std::vector<hipEvent_t> ev;   // ev[i] recorded before launch i; one more after the last
+  std::vector<hipEvent_t> ev;   // a pool created BEFORE the enqueue loop (an event created between two launches paces the host, and the
+                                // interval it opens then measures the host, not the kernel); ev[i] is recorded before launch i, one more after the last
   std::vector<int> kind;        // P2V_K_* of launch i
+  int used = 0;
+  bool make_pool(int n) {
+    ev.resize(n);
+    for (int i = 0; i < n; ++i)
+      if (hipEventCreate(&ev[i]) != hipSuccess) { ev.resize(i); return false; }
+    return true;
+  }
+  ~Prof() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
 };
+static int prof_pool_size(const p2v_plan* p) { return p ? 7 * p->d.depth + 8 : 0; }
 
 static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
                         size_t workspace_bytes, int stop_after, void* stream, Prof* prof, float* const* qkv_tap = nullptr,
@@ -373,10 +426,8 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
   do {                                                \
     if (stop_after >= 0 && launched >= stop_after) return P2V_OK; \
     if (prof) {                                       \
-      hipEvent_t e_;                                  \
-      if (hipEventCreate(&e_) != hipSuccess) return fail(P2V_E_LAUNCH, "hipEventCreate failed"); \
-      hipEventRecord(e_, st);                         \
-      prof->ev.push_back(e_);                         \
+      if (prof->used + 1 >= (int)prof->ev.size()) return fail(P2V_E_LAUNCH, "profile: event pool exhausted"); \
+      hipEventRecord(prof->ev[prof->used++], st);     \
       prof->kind.push_back(kind_);                    \
     }                                                 \
     rc = (call);                                      \
@@ -458,12 +509,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
   STEP(P2V_K_GEMM_HEAD, run_gemm(P2V_EPI_HEAD, bufCLS, D, batch, D, d.num_classes, p->lin[bit_index(bit_config[n_cfg - 1])][n_cfg - 1], eh, logits,
                 d.num_classes, nullptr, st));
 #undef STEP
-  if (prof) {
-    hipEvent_t e_;
-    if (hipEventCreate(&e_) != hipSuccess) return fail(P2V_E_LAUNCH, "hipEventCreate failed");
-    hipEventRecord(e_, st);
-    prof->ev.push_back(e_);
-  }
+  if (prof) hipEventRecord(prof->ev[prof->used++], st);
   return P2V_OK;
 }
 
@@ -478,9 +524,10 @@ int p2v_forward_taps(p2v_plan* p, const float* images, int batch, const int8_t* 
 }
 
 static int prof_collect(Prof& prof, float* ms_out, int32_t* kind_out, int max_launches) {
-  hipEventSynchronize(prof.ev.back());
-  const int n = (int)prof.kind.size();
-  for (int i = 0; i < n && i < max_launches; ++i) {
+  hipEventSynchronize(prof.ev[prof.used - 1]);
+  int n = (int)prof.kind.size();
+  n = n < max_launches ? n : max_launches;          // never more than the caller's arrays hold
+  for (int i = 0; i < n; ++i) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, prof.ev[i], prof.ev[i + 1]);
     ms_out[i] = ms;
@@ -491,24 +538,25 @@ static int prof_collect(Prof& prof, float* ms_out, int32_t* kind_out, int max_la
 
 int p2v_forward_profile(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
                         size_t workspace_bytes, void* stream, float* ms_out, int32_t* kind_out, int max_launches) {
-  if (!ms_out || !kind_out || max_launches <= 0) return fail(P2V_E_ARG, "p2v_forward_profile: null argument");
+  if (!p || !ms_out || !kind_out || max_launches <= 0) return fail(P2V_E_ARG, "p2v_forward_profile: null argument");
   Prof prof;
-  int rc = forward_impl(p, images, batch, bit_config, n_cfg, logits, workspace, workspace_bytes, -1, stream, &prof);
-  int n = 0;
-  if (rc == P2V_OK) n = prof_collect(prof, ms_out, kind_out, max_launches);
-  for (hipEvent_t e : prof.ev) hipEventDestroy(e);
-  return rc == P2V_OK ? n : rc;
+  if (!prof.make_pool(prof_pool_size(p))) return fail(P2V_E_LAUNCH, "hipEventCreate failed");
+  const int rc = forward_impl(p, images, batch, bit_config, n_cfg, logits, workspace, workspace_bytes, -1, stream, &prof);
+  return rc == P2V_OK ? prof_collect(prof, ms_out, kind_out, max_launches) : rc;
 }
 
 int p2v_forward_profile_begin(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
                               size_t workspace_bytes, void* stream, void** token) {
-  if (!token) return fail(P2V_E_ARG, "p2v_forward_profile_begin: null argument");
+  if (!p || !token) return fail(P2V_E_ARG, "p2v_forward_profile_begin: null argument");
+  *token = nullptr;
   Prof* prof = new Prof();
+  if (!prof->make_pool(prof_pool_size(p))) {
+    delete prof;
+    return fail(P2V_E_LAUNCH, "hipEventCreate failed");
+  }
   const int rc = forward_impl(p, images, batch, bit_config, n_cfg, logits, workspace, workspace_bytes, -1, stream, prof);
   if (rc != P2V_OK) {
-    for (hipEvent_t e : prof->ev) hipEventDestroy(e);
     delete prof;
-    *token = nullptr;
     return rc;
   }
   *token = prof;
@@ -516,10 +564,11 @@ int p2v_forward_profile_begin(p2v_plan* p, const float* images, int batch, const
 }
 
 int p2v_forward_profile_end(void* token, float* ms_out, int32_t* kind_out, int max_launches) {
-  if (!token || !ms_out || !kind_out || max_launches <= 0) return fail(P2V_E_ARG, "p2v_forward_profile_end: null argument");
+  if (!token) return fail(P2V_E_ARG, "p2v_forward_profile_end: null argument");
   Prof* prof = reinterpret_cast<Prof*>(token);
-  const int n = prof_collect(*prof, ms_out, kind_out, max_launches);
-  for (hipEvent_t e : prof->ev) hipEventDestroy(e);
+  int n = 0;
+  if (ms_out && kind_out && max_launches > 0) n = prof_collect(*prof, ms_out, kind_out, max_launches);
+  else hipEventSynchronize(prof->ev[prof->used - 1]);      // ms_out == NULL: just release the token (error paths of the caller)
   delete prof;
   return n;
 }

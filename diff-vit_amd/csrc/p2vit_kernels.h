@@ -1,4 +1,4 @@
-// internal launch interface between the C ABI (p2vit_capi.cpp) and the kernels (p2vit_kernels.hip)
+// internal launch interface between the C ABI (p2vit_capi.cpp) and the kernels (p2vit_gemm.hip, p2vit_ln.hip, p2vit_attn.hip, p2vit_misc.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -85,6 +85,6 @@ int p2v_launch_fake_quant(const float* x, long long n, const float* scale, int n
 int p2v_launch_gelu_quant(const float* y, long long n, float inv_s, int8_t* codes, unsigned long long* flags, int force_slow,
                           hipStream_t st);
 int p2v_launch_gelu_sweep(unsigned first_bits, unsigned count, float* max_err, hipStream_t st);
-// exact GELU->requant threshold table (see the GELU section of p2vit_kernels.hip)
+// exact GELU->requant threshold table (see the GELU section of p2vit_device.h)
 int p2v_launch_gelu_table_build(float inv_s, const p2v_gelu_tab& t, unsigned* scratch, hipStream_t st);
 int p2v_launch_gelu_table_check(float inv_s, const p2v_gelu_tab& t, unsigned long long* mismatches, hipStream_t st);

@@ -98,6 +98,7 @@ def lib():
     L.p2v_plan_set_embed.argtypes = [_p, _f, C.POINTER(Epilogue), _p]
     L.p2v_plan_set_block.argtypes = [_p, _i, C.POINTER(Block)]
     L.p2v_plan_set_head.argtypes = [_p, C.POINTER(Ln), _f, _f]
+    L.p2v_plan_block_prefolded.argtypes = [_p, _i]
     L.p2v_workspace_bytes.argtypes = [_p, _i]
     L.p2v_workspace_bytes.restype = C.c_size_t
     L.p2v_workspace_view.argtypes = [_p, _i, C.c_char_p]

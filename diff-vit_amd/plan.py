@@ -11,6 +11,7 @@ Input is a *calibration dict* (nested: name -> tensor | {bit_name: tensor} | [pe
 the format ``export_calib`` produces from the module surface; plus the fp32 ``state_dict``.
 """
 import ctypes as C
+import warnings
 import weakref
 
 import numpy as np
@@ -60,7 +61,9 @@ class FrozenPlan:
         self.arch = dict(arch)
         self.input_quant = bool(input_quant)      # False: the fp32 image feeds the patch-embed convolution (vit_fquant.py:705, :925)
         self.device = torch.device(device)
-        if self.device.type == 'cuda' and self.device.index is None:
+        if self.device.type != 'cuda':
+            raise RuntimeError('FrozenPlan needs a GPU device: the quantized forward runs on the HIP engine only (no CPU path)')
+        if self.device.index is None:
             self.device = torch.device('cuda', torch.cuda.current_device())
         self.in_chans = in_chans
         self._keep = []          # tensors whose device pointers the C plan borrows
@@ -78,7 +81,10 @@ class FrozenPlan:
                            self.hidden, a['num_classes'])
         E.check(L.p2v_plan_create(C.byref(desc), C.byref(self._handle)))
         W = {k: v.detach().float().cpu() for k, v in state_dict.items()}
-        self._build(W, calib)
+        # every upload and the plan-time fold of p2v_plan_set_block (a hipMalloc + copies) happen with the plan's device current,
+        # whichever device the caller has selected (a plan for cuda:1 built while cuda:0 is current)
+        with torch.cuda.device(self.device):
+            self._build(W, calib)
         from . import ops                      # torch.ops.p2vit.forward(handle, images, bit_config)
         ops._PLANS[self.handle] = weakref.proxy(self)
 
@@ -207,6 +213,8 @@ class FrozenPlan:
             fe.s_next = E.ptr(self._dev(s_b4))
             blk.fc2_epi = fe
             E.check(L.p2v_plan_set_block(self._handle, i, C.byref(blk)))
+            if L.p2v_plan_block_prefolded(self._handle, i) != 1:        # same results either way: the kernels then fold per workgroup
+                warnings.warn('block %d: LayerNorm constants not folded at plan time: %s' % (i, (L.p2v_last_error() or b'').decode()))
             s_res = s_b4
         # ---- head ------------------------------------------------------------------------------
         s_f = _need_pot('qact2', c['qact2'])
@@ -358,15 +366,19 @@ class FrozenPlan:
                                             E.stream_ptr(self.device), ms, kind, n_max)
         if n < 0:
             E.check(n)
-        return [(E.KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(n)]
+        return [(E.KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(min(n, n_max))]
 
     def profile_streams(self, images, bit_config, n_streams=3, slices=None, rounds=3):
         """per-launch times UNDER OVERLAP: the slices of ``forward_streams`` run concurrently on their streams, each with HIP events
         between its launches (``p2v_forward_profile_begin`` / ``_end``); ``rounds`` consecutive steps are enqueued back to back so that
-        the middle one runs in the steady state.  Returns (per-slice list of [(kind_name, ms), ...] of the middle round, wall ms of it)."""
+        the middle one runs in the steady state.  Returns (per-slice list of [(kind_name, ms), ...] of the middle round, wall ms of it).
+        A batch that runs as ONE slice has no overlap: the isolated profile is returned."""
         images, cfg = self._check(images, bit_config)
         B = images.shape[0]
         sizes = list(slices) if slices is not None else self.slice_sizes(B, n_streams)
+        if len(sizes) == 1:
+            per = self.profile(images, bit_config)
+            return [per], sum(ms for _, ms in per)
         out = torch.empty(B, self.arch['num_classes'], dtype=torch.float32, device=self.device)
         L = E.lib()
         n_max = 7 * self.depth + 8
@@ -376,28 +388,35 @@ class FrozenPlan:
             cur = torch.cuda.current_stream(self.device)
             n_side = min(len(sizes), max(n_streams, 1))
             tokens = []
-            for r in range(rounds):
-                lo = hi = 0
-                row = []
-                for i, n_i in enumerate(sizes):
-                    lo, hi = hi, hi + n_i
-                    st = self._streams[i] if i < n_side else cur
-                    tok = C.c_void_p()
-                    E.check(L.p2v_forward_profile_begin(self._handle, E.ptr(images[lo:hi]), n_i, cfg, len(bit_config), E.ptr(out[lo:hi]),
-                                                        E.ptr(self._ws_multi[i]), self._ws_multi[i].numel(), C.c_void_p(st.cuda_stream), C.byref(tok)))
-                    row.append(tok)
-                tokens.append(row)
-            res = []
-            for r, row in enumerate(tokens):
-                per = []
-                for tok in row:
-                    ms = (C.c_float * n_max)()
-                    kind = (C.c_int32 * n_max)()
-                    n = L.p2v_forward_profile_end(tok, ms, kind, n_max)
-                    if n < 0:
-                        E.check(n)
-                    per.append([(E.KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(n)])
-                res.append(per)
+            try:
+                for r in range(rounds):
+                    lo = hi = 0
+                    row = []
+                    tokens.append(row)
+                    for i, n_i in enumerate(sizes):
+                        lo, hi = hi, hi + n_i
+                        st = self._streams[i] if i < n_side else cur
+                        tok = C.c_void_p()
+                        E.check(L.p2v_forward_profile_begin(self._handle, E.ptr(images[lo:hi]), n_i, cfg, len(bit_config), E.ptr(out[lo:hi]),
+                                                            E.ptr(self._ws_multi[i]), self._ws_multi[i].numel(), C.c_void_p(st.cuda_stream), C.byref(tok)))
+                        row.append(tok)
+                res = []
+                for row in tokens:
+                    per = []
+                    for j, tok in enumerate(row):
+                        ms = (C.c_float * n_max)()
+                        kind = (C.c_int32 * n_max)()
+                        row[j] = None                                                     # ended (also when the call below fails)
+                        n = L.p2v_forward_profile_end(tok, ms, kind, n_max)
+                        if n < 0:
+                            E.check(n)
+                        per.append([(E.KERNEL_KINDS[kind[i]], float(ms[i])) for i in range(min(n, n_max))])
+                    res.append(per)
+            finally:                         # a failed begin / end must not leak the tokens (events + bookkeeping) already handed out
+                for row in tokens:
+                    for tok in row:
+                        if tok is not None:
+                            L.p2v_forward_profile_end(tok, None, None, 0)
         mid = res[len(res) // 2]
         return mid, max(sum(ms for _, ms in per) for per in mid)
 

@@ -43,7 +43,8 @@ class SwinPlan:
         self.W = {k: v.detach().float().cpu() for k, v in state_dict.items() if v.dtype == torch.float32}
         self.c = calib
         self._recorded = {}
-        self._build()
+        with torch.cuda.device(self.device):      # uploads and GELU-table builds on the plan's device, whatever the caller's current one
+            self._build()
 
     # ---- helpers -------------------------------------------------------------------------------------------------------
     def _dev(self, t, dtype=torch.float32):

@@ -185,8 +185,15 @@ typedef struct p2v_block {
 /* Stores the block's constants (the arrays stay the caller's and must outlive the plan) and - since round 3 - reads the LayerNorm arrays
  * back once to fold gamma / out_scale and beta / out_scale and to run the fast-chain tests on the host, so that the kernels of p2v_forward
  * do not repeat that per workgroup.  The call therefore synchronises the device (hipDeviceSynchronize) and must come after the arrays have
- * been written; changing an array afterwards requires setting the block again.  The folded copies are owned by the plan. */
+ * been written; changing an array afterwards requires setting the block again.  The folded copies are owned by the plan and live on the
+ * device that owns blk->ln1[0].gamma (found with hipPointerGetAttributes - the process's current device does not matter; all blocks of a
+ * plan must live on one device).  If the fold cannot be done (a HIP error, arrays on another device than earlier blocks) the call still
+ * returns P2V_OK - the kernels then fold per workgroup, with identical results - and leaves the reason in p2v_last_error();
+ * p2v_plan_block_prefolded() tells which of the two a block got. */
 int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk);
+/* 1: the LayerNorm constants of the block were folded when it was set; 0: its kernels fold per workgroup (p2v_last_error() of the
+ * p2v_plan_set_block call says why); negative: error. */
+int p2v_plan_block_prefolded(const p2v_plan* plan, int block);
 
 int p2v_plan_set_head(p2v_plan* plan, const p2v_ln* final_ln, float inv_s_out, float s_out);
 
@@ -223,7 +230,10 @@ int p2v_forward_profile(p2v_plan* plan, const float* images, int batch, const in
 /* The same measurement for forwards that run CONCURRENTLY on several streams (the batch slices of the default step): _begin enqueues
  * the forward with its events on `stream` and returns at once with a token; _end synchronises on that forward's last event, fills
  * ms_out / kind_out like p2v_forward_profile, frees the token and returns the number of launches.  Begin every slice first, then end
- * them: ms_out[i] is then the duration of launch i WHILE the other streams' kernels run. */
+ * them: ms_out[i] is then the duration of launch i WHILE the other streams' kernels run.  Every token must be ended; _end with
+ * ms_out == NULL only waits for the forward and frees the token (error paths).  The events of a pass are created before its first
+ * launch is enqueued (an event created between two launches would pace the host and the interval would measure the host), and the
+ * returned count never exceeds max_launches. */
 int p2v_forward_profile_begin(p2v_plan* plan, const float* images, int batch, const int8_t* bit_config, int n_cfg,
                               float* logits, void* workspace, size_t workspace_bytes, void* stream, void** token);
 int p2v_forward_profile_end(void* token, float* ms_out, int32_t* kind_out, int max_launches);
@@ -371,7 +381,7 @@ int p2v_abi_version(void);
  * P2V_LN_ROWS, P2V_ATTN_WAVES, P2V_GEMM_STAGES, P2V_GEMM_TILE).  None of them changes a result - every variant is bit-identical and is driven
  * through this call by the parity tests:
  *   "ln_gemm" 0/1 (fuse LayerNorm into qkv / fc1), "ln_gemm_version" 1/2 (4-wave / 8-wave pipelined fused kernel),
- *   "ln_generic" 0/1 (generic LayerNorm chain), "ln_rows" 1..64, "attn_waves" 4..8, "gemm_stages" 2/3,
+ *   "ln_generic" 0/1 (generic LayerNorm chain), "ln_rows" 1..64, "attn_waves" 4..8,
  *   "gemm_tile" 0/128/256 (tile height of the layer GEMMs; 0 = 256 rows when the grid still fills the chip). */
 int p2v_set_tuning(const char* name, int value);
 

@@ -306,7 +306,12 @@ def weight_codes(w, cs, scale, bit):
 def qgemm(x_codes, s_x, w_codes, s_w, bias):
     """F.linear on fake-quantised operands: exact integer accumulation, scale, then ONE rounding for the
     fp32 bias add."""
-    acc = x_codes @ w_codes.t()          # integer valued, |acc| < 2^24  -> exact in fp32
+    # integer-valued sum of products accumulated in fp64 (exact below 2^53 whatever the order), then ENFORCED to fit fp32's 24 bits:
+    # the reference's fp32 F.linear is order-independent only under that bound, and so is the cast below
+    acc = x_codes.double() @ w_codes.double().t()
+    amax = float(acc.abs().max()) if acc.numel() else 0.0
+    assert amax < 2.0 ** 24, 'qgemm: |acc| = %g does not fit 24 bits: the reference result would depend on the summation order' % amax
+    acc = acc.float()
     y = acc * (s_x * s_w).reshape(1, -1)
     return y + bias if bias is not None else y
 

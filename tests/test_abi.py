@@ -117,10 +117,10 @@ def test_tuning_switches():
     import diff_vit_amd
     E = diff_vit_amd.engine
     L = E.lib()
-    for name, good, bad in ((b'ln_gemm_version', 3, 4), (b'ln_rows', 4, 0), (b'attn_waves', 8, 9), (b'gemm_stages', 3, 5)):
+    for name, good, bad in ((b'ln_gemm_version', 3, 4), (b'ln_rows', 4, 0), (b'attn_waves', 8, 9), (b'gemm_tile', 128, 64)):
         assert L.p2v_set_tuning(name, good) == 0
         assert L.p2v_set_tuning(name, bad) == E.E_ARG
-    assert L.p2v_set_tuning(b'ln_gemm_version', 2) == 0 and L.p2v_set_tuning(b'ln_gemm', 1) == 0 and L.p2v_set_tuning(b'ln_generic', 0) == 0
+    assert L.p2v_set_tuning(b'gemm_tile', 0) == 0 and L.p2v_set_tuning(b'ln_gemm_version', 2) == 0 and L.p2v_set_tuning(b'ln_gemm', 1) == 0 and L.p2v_set_tuning(b'ln_generic', 0) == 0
     assert L.p2v_set_tuning(b'no_such_switch', 1) == E.E_ARG and L.p2v_set_tuning(None, 1) == E.E_ARG
     assert b'unknown switch' in L.p2v_last_error() or b'null name' in L.p2v_last_error()
 
@@ -192,3 +192,22 @@ def test_int4_tile_packing_layout():
         row, k0 = 128 * t + 32 * wave + r, 32 * ks + 16 * h
         lo_k, hi_k = (k0 + j, k0 + 4 + j) if j < 4 else (k0 + 8 + (j - 4), k0 + 12 + (j - 4))
         assert f[t, wave, ks, h, r, j] == ((wn[row, lo_k] & 15) | ((wn[row, hi_k] & 15) << 4)), (t, wave, ks, h, r, j)
+
+
+def test_late_import_warns_about_hardware_queues():
+    """GPU_MAX_HW_QUEUES=8 is only a default the package can set BEFORE the HIP runtime initialises: an import that comes too late (HIP up,
+    variable unset) warns and records `in_effect: False`; a user setting or an early import does not."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    late = ("import sys, warnings; sys.path.insert(0, %r); import torch; torch.cuda.is_initialized = lambda: True\n"
+            "with warnings.catch_warnings(record=True) as w:\n"
+            "    warnings.simplefilter('always'); import diff_vit_amd as d\n"
+            "print(int(any('GPU_MAX_HW_QUEUES' in str(x.message) for x in w)), int(d.HW_QUEUES['in_effect']), d.HW_QUEUES['set_by'])\n" % root)
+    r = subprocess.run([sys.executable, '-c', late], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.split()[:2] == ['1', '0'], r.stdout + r.stderr
+    r = subprocess.run([sys.executable, '-c', late], capture_output=True, text=True, env=dict(env, GPU_MAX_HW_QUEUES='6'), timeout=300)
+    assert r.returncode == 0 and r.stdout.split()[:3] == ['0', '1', 'environment'], r.stdout + r.stderr
+    early = "import sys; sys.path.insert(0, %r); import diff_vit_amd as d; print(int(d.HW_QUEUES['in_effect']), d.HW_QUEUES['value'])" % root
+    r = subprocess.run([sys.executable, '-c', early], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.split() == ['1', '8'], r.stdout + r.stderr

@@ -83,6 +83,14 @@ def test_pretrained_true_reads_the_torch_hub_cache(tmp_path, monkeypatch):
     arch = dva.synth.ARCHS['deit_tiny']
     sd = dva.synth.vit_state_dict(arch, 5)
     torch.save({'model': sd}, ck.pretrained_path('deit_tiny_patch16_224'))
+    # torch.hub's check_hash=True (what the reference's factory calls): the digest must start with the hex suffix of the file name
+    with pytest.raises(RuntimeError, match='invalid hash value'):
+        dva.deit_tiny_patch16_224(pretrained=True)
+    import hashlib
+    digest = hashlib.sha256(open(ck.pretrained_path('deit_tiny_patch16_224'), 'rb').read()).hexdigest()
+    good = 'deit_tiny_patch16_224-%s.pth' % digest[:8]
+    os.rename(ck.pretrained_path('deit_tiny_patch16_224'), os.path.join(str(tmp_path), 'hub', 'checkpoints', good))
+    monkeypatch.setitem(ck.PRETRAINED_FILES, 'deit_tiny_patch16_224', good)
     m = dva.deit_tiny_patch16_224(pretrained=True)
     assert all(torch.equal(m.state_dict()[k], v) for k, v in sd.items())
     # the Flax layout of the ViT-B factory (models/utils.py:12-197)

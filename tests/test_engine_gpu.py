@@ -758,6 +758,18 @@ def test_fp_input_model_engine_vs_reference_golden(dva, oracle, synth):
         assert np.array_equal(out.numpy(), g['logits/' + tag]), tag
         assert np.array_equal(out.topk(5, 1, True, True)[1].numpy(), g['top5/' + tag]), tag
         assert torch.equal(out, orc.quant_forward(x, bc)), tag
+    # the plan file carries input_quant: a save / load round trip of this configuration rebuilds the fp32-image stem
+    import tempfile, os
+    from diff_vit_amd import calib_io
+    with tempfile.TemporaryDirectory() as td:
+        calib_io.save_plan(os.path.join(td, 'fp_in.npz'), m)
+        plan = calib_io.load_plan(os.path.join(td, 'fp_in.npz'))
+        assert plan.input_quant is False
+        assert np.array_equal(plan.forward(x.cuda(), _bits(g, 'q8', 10)).cpu().numpy(), g['logits/q8'])
+    # every block's LayerNorm constants were folded when the plan was built (p2v_plan_block_prefolded), on the plan's own device
+    L = dva.engine.lib()
+    assert all(L.p2v_plan_block_prefolded(m._plan._handle, i) == 1 for i in range(a['depth']))
+    assert L.p2v_plan_block_prefolded(m._plan._handle, a['depth']) < 0
 
 
 def test_custom_ops_match_c_abi(dva, oracle, micro):
@@ -1057,8 +1069,13 @@ def test_bench_two_ranks_on_one_gpu_gloo(dva):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
-                        '--repeats', '2', '--batch', '12', '--model', 'deit_tiny', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, env=env)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
+           '--repeats', '2', '--batch', '12', '--model', 'deit_tiny', '--no-cpu-baseline']
+    if torch.cuda.device_count() < 2:
+        # more ranks than GPUs without the rehearsal flag: a loud refusal before anything touches the GPU, never an "N-GPU" number
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode != 0 and 'refusing to stack ranks' in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith('{')]
+    r = subprocess.run(cmd + ['--share-device'], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -1066,6 +1083,11 @@ def test_bench_two_ranks_on_one_gpu_gloo(dva):
     assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak' and d['config']['global_batch'] == 24
     assert d['config']['gathered_logits_equal_per_rank_forwards'] is True
     assert d['value'] > 0 and 'roofline' in d and d['cpu_baseline'] is None
+    # the line says what the GROUP saw: two ranks, their devices, and - on a one-GPU box - that they shared one
+    c = d['config']
+    assert c['ranks_seen'] == 2 and len(c['devices']) == 2 and c['distinct_devices'] == min(2, torch.cuda.device_count())
+    assert c['shared_device_rehearsal'] is (torch.cuda.device_count() < 2)
+    assert c['gpu_max_hw_queues']['value'] == os.environ.get('GPU_MAX_HW_QUEUES', '8') and c['gpu_max_hw_queues']['in_effect'] is True
 
 
 def test_bench_rccl_branch_on_one_gpu(dva):
@@ -1090,6 +1112,10 @@ def test_bench_rccl_branch_on_one_gpu(dva):
     d = json.loads(lines[0])
     assert d['n_gpus'] == 1 and d['config']['backend'] == 'nccl' and d['config']['collective'] == 'all_gather(logits)'
     assert d['config']['gathered_logits_equal_per_rank_forwards'] is True and d['value'] > 0
+    c = d['config']
+    assert c['ranks_seen'] == 1 and c['distinct_devices'] == 1 and len(c['devices']) == 1 and c['shared_device_rehearsal'] is False
+    assert c['gpu_max_hw_queues']['in_effect'] is True
+    assert d['roofline']['dominant_by'] and d['roofline']['launch_us']['median'] > 0
 
 
 @pytest.mark.parametrize('M,K,N', [(777, 128, 256), (1000, 448, 384), (261, 768, 128)])

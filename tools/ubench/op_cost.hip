@@ -1,5 +1,5 @@
 // Saturated issue cost (cycles per wave64 instruction and SIMD, at 1 / 2 / 4 waves per SIMD) of the individual VALU instructions the
-// epilogue chains of p2vit_kernels.hip are made of (gfx950).  Eight independent destination registers per instruction kind.
+// epilogue chains of p2vit_{gemm,ln,attn,misc}.hip are made of (gfx950).  Eight independent destination registers per instruction kind.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #define ITER 1024
