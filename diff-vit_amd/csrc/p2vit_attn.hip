@@ -14,6 +14,21 @@
 //   ~100 VGPRs -> 4 waves/SIMD, 3 workgroups (47 KB LDS each) per CU.
 // ---------------------------------------------------------------------------------------------------
 
+// log_round + the uint4 clamp of two ratios at once (layers.py:323-329, 372-375): E = (bits + 0x00400000) >> 23 is the biased exponent of 2^k
+// (ratio >= 1, so k = E - 127 >= 0) and the probability is 2^-k, or 0 from k = 16 on.  It goes into the P.V product as bf16 SCALED BY
+// 2^-111: exponent field 16 - k, i.e. (143 - E) << 7 with an UNSIGNED-SATURATING subtraction (v_pk_sub_u16 clamp) - from k = 16 on the field
+// saturates to the all-zero pattern, which IS +0.0, so the clamp costs nothing (round 3: (254 - E) << 7, a second subtraction, a shift and an
+// and-not to zero the small ones).  The scaled probabilities are normal bf16 numbers >= 2^-126, the products with the integer V codes and their
+// fp32 sums are multiples of 2^-126 below 2^-102: still exact in 24 bits, none denormal; the 2^111 is folded into av_mul (a power of two).
+#define P2V_PROB_SCALE 0x1p111f
+__device__ __forceinline__ unsigned lis_prob_pair(float r0, float r1) {
+  const unsigned hi2 = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+  const unsigned eb = __builtin_bit_cast(unsigned, __builtin_bit_cast(v2u16, hi2) + (v2u16){0x40, 0x40}) & 0x7F807F80u;      // E << 7, twice
+  unsigned out;
+  asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(out) : "v"(0x47804780u), "v"(eb));                                          // sat((143 - E) << 7)
+  return out;
+}
+
 // ISH: the score multiplier qk_scale * s_q1^2 / s_attn is 2^-pshift with pshift >= 1 (head_dim 64: qk_scale = 1/8): the qact_attn1
 // codes come from an integer round-half-even shift instead of the fp32 cvt / mul / rndne / med3 / cvt chain (2.5 VALU per score less)
 #ifdef P2V_DIAG
@@ -110,6 +125,7 @@ __global__ __launch_bounds__(512, NKP <= 7 ? 4 : (NKP <= 10 ? 3 : 2)) void k_lis
   // s_q1^2 / s_attn is a power of two (checked by the launcher), so ((acc * qk_scale) * 2^e) == acc * (qk_scale * 2^e)
   // with the same single rounding; the NEGATED code is produced (round-half-even and the clamp are symmetric).
   const float nmm = -(a.at.qk_scale * (a.at.s_qkv_sq * a.at.inv_s_attn));
+  const float avm = a.at.av_mul * P2V_PROB_SCALE;        // the probabilities enter the P.V product scaled by 2^-111 (lis_prob_pair); exact, checked by the launcher
   const int nqb = (N + 15) >> 4;
   const int nwaves = (int)(blockDim.x >> 6);
   // the Q fragment of a wave's first query block is requested before the barrier and the one of its next block a block ahead: its
@@ -253,13 +269,7 @@ __global__ __launch_bounds__(512, NKP <= 7 ? 4 : (NKP <= 10 ? 3 : 2)) void k_lis
             a.probs_k[(((long long)b * a.H + head) * N + qrow) * N + kb * 16 + 4 * g + r] = (int8_t)(k > 16 ? 16 : k);
           }
         }
-        // log_round on the two high halves at once: E = (bits + 0x00400000) >> 23 is the biased exponent of 2^k
-        // (ratio >= 1 so k >= 0); 2^-k as bf16 is (254 - E) << 7, and k >= 16 (E >= 143) -> 0   (layers.py:372-375)
-        const unsigned hi2 = __builtin_amdgcn_perm(__float_as_uint(ratio[1]), __float_as_uint(ratio[0]), 0x07060302u);
-        const v2u16 eb = __builtin_bit_cast(v2u16, (__builtin_bit_cast(unsigned, __builtin_bit_cast(v2u16, hi2) + (v2u16){0x40, 0x40})) & 0x7F807F80u);
-        const v2u16 hb = (v2u16){0x7F00, 0x7F00} - eb;                                  // (254 - E) << 7
-        const v2i16 neg = __builtin_bit_cast(v2i16, (v2u16)(hb - (v2u16){0x3800, 0x3800})) >> (v2i16){15, 15};   // all ones where k >= 16
-        pk[e2] = __builtin_bit_cast(unsigned, hb) & ~__builtin_bit_cast(unsigned, neg);
+        pk[e2] = lis_prob_pair(ratio[0], ratio[1]);              // 2^-k * 2^-111 as bf16, 0 from k = 16 on
       }
       v4i pb = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
       const v8bf fb = __builtin_bit_cast(v8bf, pb);
@@ -286,8 +296,7 @@ __global__ __launch_bounds__(512, NKP <= 7 ? 4 : (NKP <= 10 ? 3 : 2)) void k_lis
       int8_t* dst = a.out + ((long long)b * N + qs) * D + head * HD + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt)
-        *reinterpret_cast<unsigned*>(dst + dt * 16) =
-            pack4_rne_sat(o[dt][0] * a.at.av_mul, o[dt][1] * a.at.av_mul, o[dt][2] * a.at.av_mul, o[dt][3] * a.at.av_mul);
+        store_out4(dst + dt * 16, pack4_rne_sat(o[dt][0] * avm, o[dt][1] * avm, o[dt][2] * avm, o[dt][3] * avm));
     }
     AT_STAMP(stamp_base + 3);
     stamp_base += 4;
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(256, 3) void k_window_attention(WinAttnArgs a) {
   const double sig_int = (double)sig_m;
   const float x_mul = ((1.0f / inv_u) * a.wa.s_q1) * inv_sa;                   // u / s_attn: a power of two
   const float m100 = (float)(int)(100.0f * inv_s2);                            // 100 / sf as an integer
-  const float av_mul = a.wa.s_q1 / a.wa.s_q3;
+  const float av_mul = (a.wa.s_q1 / a.wa.s_q3) * P2V_PROB_SCALE;            // the probabilities are scaled by 2^-111 (lis_prob_pair)
   const int c0 = (ws - 1) * (2 * ws - 1) + (ws - 1);
   const int nqb = (N + 15) >> 4;
   // per score slot of this lane: relative-position term and region of its key (the same for every query block)
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(256, 3) void k_window_attention(WinAttnArgs a) {
       const int E = (int)((__float_as_uint(ratio) + 0x00400000u) >> 23);         // biased exponent of 2^k
       if (TAP && valid)
         a.probs_k[((((long long)b * nW + w) * a.H + head) * N + (N - 1)) * N + j] = (int8_t)(E - 127 > 16 ? 16 : E - 127);
-      sP[wave][g][l15] = (unsigned short)((E < 143 && l15 < 13) ? (254 - E) << 7 : 0);     // 2^-k as bf16, 0 from k = 16 (and for padding: sum / 1 >= 2^32)
+      sP[wave][g][l15] = (unsigned short)((E < 143 && l15 < 13) ? (143 - E) << 7 : 0);     // 2^-k * 2^-111 as bf16 (lis_prob_pair), 0 from k = 16 (and for padding: sum / 1 >= 2^32)
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
       pb[0] = *reinterpret_cast<const v4i*>(&sP[wave][g][0]);                  // slots 0-7 = key blocks 0, 1;  8-15 = key blocks 2, 3 (13-15: zero)
@@ -567,12 +576,7 @@ __global__ __launch_bounds__(256, 3) void k_window_attention(WinAttnArgs a) {
               a.probs_k[((((long long)b * nW + w) * a.H + head) * N + qi) * N + kb * 16 + 4 * g + r] = (int8_t)(k > 16 ? 16 : k);
             }
           }
-          // log_round and the clamp at 16 on the two high halves at once, see k_lis_attention
-          const unsigned hi2 = __builtin_amdgcn_perm(__float_as_uint(ratio[1]), __float_as_uint(ratio[0]), 0x07060302u);
-          const v2u16 eb = __builtin_bit_cast(v2u16, (__builtin_bit_cast(unsigned, __builtin_bit_cast(v2u16, hi2) + (v2u16){0x40, 0x40})) & 0x7F807F80u);
-          const v2u16 hb = (v2u16){0x7F00, 0x7F00} - eb;                                  // (254 - E) << 7
-          const v2i16 neg = __builtin_bit_cast(v2i16, (v2u16)(hb - (v2u16){0x3800, 0x3800})) >> (v2i16){15, 15};   // all ones where k >= 16
-          pk[e2] = __builtin_bit_cast(unsigned, hb) & ~__builtin_bit_cast(unsigned, neg);
+          pk[e2] = lis_prob_pair(ratio[0], ratio[1]);            // 2^-k * 2^-111 as bf16, 0 from k = 16 on (see k_lis_attention)
         }
         pb[p] = (v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
       }
@@ -594,8 +598,7 @@ __global__ __launch_bounds__(256, 3) void k_window_attention(WinAttnArgs a) {
       int8_t* dst = a.out + ((long long)b * a.T + rowq) * ldo + head * WA_HD + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
-        *reinterpret_cast<unsigned*>(dst + dt * 16) =
-            pack4_rne_sat(o[dt][0] * av_mul, o[dt][1] * av_mul, o[dt][2] * av_mul, o[dt][3] * av_mul);
+        store_out4(dst + dt * 16, pack4_rne_sat(o[dt][0] * av_mul, o[dt][1] * av_mul, o[dt][2] * av_mul, o[dt][3] * av_mul));
     }
   }
 }

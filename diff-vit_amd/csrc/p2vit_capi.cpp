@@ -62,6 +62,10 @@ static int check_attn(const char* who, const p2v_attn& at) {
   // the kernel folds s_q1^2 / s_attn into qk_scale: exact only for a power of two (both are PoT scales in the reference)
   if (!is_pot(at.s_qkv_sq * at.inv_s_attn)) return fail(P2V_E_UNSUPPORTED, "%s: s_qkv_sq * inv_s_attn must be a power of two", who);
   if (!(at.qk_scale > 0.f) || !(at.av_mul > 0.f)) return fail(P2V_E_ARG, "%s: qk_scale and av_mul must be positive", who);
+  // the probabilities enter the P.V product scaled by 2^-111 and av_mul carries the 2^111 (p2vit_attn.hip, lis_prob_pair): exact for a
+  // power of two in this range (s_q1 / qact2 scale of two PoT activation scales)
+  if (!is_pot(at.av_mul) || at.av_mul > 0x1p15f || at.av_mul < 0x1p-40f)
+    return fail(P2V_E_UNSUPPORTED, "%s: av_mul %g must be a power of two in [2^-40, 2^15]", who, at.av_mul);
   return P2V_OK;
 }
 
@@ -84,16 +88,23 @@ struct p2v_plan {
   std::vector<LnPre> ln_pre;
   std::vector<float*> ln_pre_buf;
   std::vector<char> block_folded;
+  // tables of the pre-folded RESID epilogue (p2v_resid_prefold): [block][proj = 0 / fc2 = 1][bit index]; null = the generic epilogue.  One device
+  // buffer per block, owned by the plan
+  std::vector<const float*> resid_tab;
+  std::vector<float*> resid_buf;
   int device = -1;                  // the device that owns the folded constants (= the device of the caller's arrays)
   ~p2v_plan() {
     int prev = -1;
     const bool sw = device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device && hipSetDevice(device) == hipSuccess;
     for (float* b : ln_pre_buf)
       if (b) (void)hipFree(b);
+    for (float* b : resid_buf)
+      if (b) (void)hipFree(b);
     if (sw) (void)hipSetDevice(prev);
   }
 };
 
+static void build_resid_tables(p2v_plan* plan, int block);
 static int bit_index(int bits) { return bits == 4 ? 0 : (bits == 8 ? 1 : -1); }
 
 extern "C" {
@@ -104,6 +115,7 @@ extern int g_attn_waves;
 extern int g_ln_gemm;
 extern int g_ln_gemm_ver;
 extern int g_gemm_tile;
+extern int g_resid_pre;
 // Tuning / A-B switches read once per process (first plan or first version query).  None of them changes results:
 // P2V_LN_GENERIC forces the generic LayerNorm chain (bit-identical to the fast one, both are tested).
 static void read_env_once() {
@@ -118,6 +130,8 @@ static void read_env_once() {
   if (e && atoi(e) >= 1 && atoi(e) <= 3) g_ln_gemm_ver = atoi(e);
   e = getenv("P2V_GEMM_TILE");
   if (e && (atoi(e) == 0 || atoi(e) == 128 || atoi(e) == 256)) g_gemm_tile = atoi(e);
+  e = getenv("P2V_RESID_PRE");
+  if (e) g_resid_pre = atoi(e) != 0;
   e = getenv("P2V_LN_ROWS");
   if (e && atoi(e) >= 1 && atoi(e) <= 64) g_ln_rows = atoi(e);
   e = getenv("P2V_LN_GENERIC");
@@ -133,6 +147,7 @@ int p2v_set_tuning(const char* name, int value) {
   if (!strcmp(name, "ln_generic")) { g_ln_generic = value != 0; return P2V_OK; }
   if (!strcmp(name, "ln_rows") && value >= 1 && value <= 64) { g_ln_rows = value; return P2V_OK; }
   if (!strcmp(name, "attn_waves") && value >= 4 && value <= 8) { g_attn_waves = value; return P2V_OK; }
+  if (!strcmp(name, "resid_pre")) { g_resid_pre = value != 0; return P2V_OK; }
   if (!strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) { g_gemm_tile = value; return P2V_OK; }
   return fail(P2V_E_ARG, "p2v_set_tuning: unknown switch or value out of range: %s = %d", name, value);
 }
@@ -171,6 +186,8 @@ int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
   p->ln_pre.assign((size_t)d.depth * 6, LnPre{nullptr, nullptr, 0.f, 0.f, 0.f, 0, 0});
   p->ln_pre_buf.assign(d.depth, nullptr);
   p->block_folded.assign(d.depth, 0);
+  p->resid_tab.assign((size_t)d.depth * 4, nullptr);
+  p->resid_buf.assign(d.depth, nullptr);
   p->embed_set = p->head_set = false;
   p->cls_codes = nullptr;
   *out = p;
@@ -188,6 +205,10 @@ int p2v_plan_set_linear(p2v_plan* plan, int layer, int bits, const p2v_linear* l
   if (lin->packed4 && bits != 4) return fail(P2V_E_BITS, "packed4 weights for a %d-bit layer", bits);
   plan->lin[bi][layer] = *lin;
   plan->lin_set[bi][layer] = 1;
+  if (layer >= 1 && layer < plan->n_layers - 1 && ((layer - 1) & 1)) {         // proj / fc2 of block (layer - 1) / 4: their RESID tables depend on these constants
+    const int block = (layer - 1) / 4;
+    if (plan->block_set[block]) build_resid_tables(plan, block);
+  }
   return P2V_OK;
 }
 
@@ -199,6 +220,72 @@ int p2v_plan_set_embed(p2v_plan* plan, float inv_s_input, const p2v_epilogue* e,
   plan->cls_codes = cls_row_codes;
   plan->embed_set = true;
   return P2V_OK;
+}
+
+// Make the device that owns `ptr` current for the lifetime of the object (plan-time folds run hipMalloc / copies / small kernels next to the
+// caller's arrays, whatever device the process has selected); ok() is false when the owner cannot be determined.
+struct OwnerDevice {
+  int prev = -1, own = -1;
+  explicit OwnerDevice(const void* ptr) {
+    hipPointerAttribute_t pa;
+    if (hipGetDevice(&prev) != hipSuccess || hipPointerGetAttributes(&pa, ptr) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    own = pa.device;
+    if (own != prev && hipSetDevice(own) != hipSuccess) own = -1;
+  }
+  ~OwnerDevice() { if (own >= 0 && own != prev) (void)hipSetDevice(prev); }
+  bool ok() const { return own >= 0; }
+};
+
+static size_t resid_tab_floats(int N) { return (size_t)((N + 127) / 128) * 6 * 128; }
+
+// build one table on the current device; *usable = 0 when the pre-folded form is not provably the reference's for these constants
+static int resid_prefold_impl(const p2v_linear& lin, const p2v_epilogue& ep, int N, float* tab, int* usable, hipStream_t st) {
+  *usable = 0;
+  unsigned* flags = nullptr;
+  hipError_t e = hipMalloc(&flags, 2 * sizeof(unsigned));
+  const unsigned init[2] = {1u, 0u};
+  unsigned got[2] = {0u, 0u};
+  if (e == hipSuccess) e = hipMemcpyAsync(flags, init, sizeof init, hipMemcpyHostToDevice, st);
+  int rc = 0;
+  if (e == hipSuccess) rc = p2v_launch_resid_prefold(lin, ep, N, tab, flags, st);
+  if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(got, flags, sizeof got, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && rc == 0) e = hipStreamSynchronize(st);
+  if (flags) (void)hipFree(flags);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(P2V_E_LAUNCH, "resid_prefold: %s", hipGetErrorString(e));
+  }
+  if (rc) return launch_rc(rc, "resid_prefold");
+  *usable = got[0] ? 1 : 0;
+  return P2V_OK;
+}
+
+// (Re)build the RESID tables of a block for every bit width whose weights are set; called from both setters, whichever comes last.
+static void build_resid_tables(p2v_plan* plan, int block) {
+  for (int j = 0; j < 4; ++j) plan->resid_tab[(size_t)block * 4 + j] = nullptr;
+  if (!plan->block_set[block]) return;
+  const p2v_block& blk = plan->blocks[block];
+  OwnerDevice dev(blk.proj_epi.s_mid);
+  if (!dev.ok() || (plan->device >= 0 && plan->device != dev.own)) return;
+  const int D = plan->d.embed_dim;
+  const size_t per = resid_tab_floats(D);
+  if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return; }      // the caller's uploads may still be in flight
+  float* buf = plan->resid_buf[block];
+  if (!buf && hipMalloc(&buf, 4 * per * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return; }
+  plan->resid_buf[block] = buf;
+  plan->device = dev.own;
+  for (int which = 0; which < 2; ++which)
+    for (int bi = 0; bi < 2; ++bi) {
+      const int layer = 1 + 4 * block + (which ? 3 : 1);
+      if (!plan->lin_set[bi][layer]) continue;
+      int usable = 0;
+      float* tab = buf + (size_t)(which * 2 + bi) * per;
+      if (resid_prefold_impl(plan->lin[bi][layer], which ? blk.fc2_epi : blk.proj_epi, D, tab, &usable, nullptr) == P2V_OK && usable)
+        plan->resid_tab[(size_t)block * 4 + which * 2 + bi] = tab;
+    }
 }
 
 // The fold of ln_prepare (p2vit_ln.hip), once per plan instead of once per workgroup: the same fp32 products and the same tests on the
@@ -300,12 +387,25 @@ int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk) {
   // is left in p2v_last_error() and p2v_plan_block_prefolded() tells
   g_err[0] = 0;
   plan->block_folded[block] = fold_ln_constants(plan, block) ? 1 : 0;
+  {
+    char keep[sizeof g_err];
+    memcpy(keep, g_err, sizeof keep);
+    build_resid_tables(plan, block);        // unusable tables simply leave the generic RESID epilogue in place
+    memcpy(g_err, keep, sizeof keep);
+  }
   return P2V_OK;
 }
 
 int p2v_plan_block_prefolded(const p2v_plan* plan, int block) {
   if (!plan || block < 0 || block >= plan->d.depth) return fail(P2V_E_ARG, "p2v_plan_block_prefolded: bad argument");
   return plan->block_folded[block] ? 1 : 0;
+}
+
+int p2v_plan_resid_prefolded(const p2v_plan* plan, int block) {
+  if (!plan || block < 0 || block >= plan->d.depth) return fail(P2V_E_ARG, "p2v_plan_resid_prefolded: bad argument");
+  int m = 0;
+  for (int j = 0; j < 4; ++j) m |= plan->resid_tab[(size_t)block * 4 + j] ? 1 << j : 0;
+  return m;
 }
 
 int p2v_plan_set_head(p2v_plan* plan, const p2v_ln* final_ln, float inv_s_out, float s_out) {
@@ -479,6 +579,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     // proj -> qact3 -> + x -> Block.qact2                                   vit_fquant.py:334-338,431
     p2v_epilogue ep = b.proj_epi;
     ep.residual = bufX;
+    ep.resid_tab = p->resid_tab[(size_t)i * 4 + bp];
     STEP(P2V_K_GEMM_PROJ, run_gemm(P2V_EPI_RESID, bufATT, D, M, D, D, p->lin[bp][2 + 4 * i], ep, bufX, D, nullptr, st));
     // norm2 (attention's channel scale!) -> /mlp.channel_scale -> mlp.qact0 vit_fquant.py:464, layers_quant.py:305-311
     LnArgs ln2{bufX, D, M, D, b.ln2[bq][b1], bufLN, D};
@@ -498,6 +599,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     // fc2 -> qact2 -> + x -> Block.qact4                                    layers_quant.py:342-346, vit_fquant.py:468
     p2v_epilogue e2 = b.fc2_epi;
     e2.residual = bufX;
+    e2.resid_tab = p->resid_tab[(size_t)i * 4 + 2 + b2];
     STEP(P2V_K_GEMM_FC2, run_gemm(P2V_EPI_RESID, bufHID, Hd, M, Hd, D, p->lin[b2][4 + 4 * i], e2, bufX, D, nullptr, st));
   }
   // norm over the cls rows only ([:,0]) -> qact2 -> head -> act_out         vit_fquant.py:766-796
@@ -596,6 +698,19 @@ int p2v_gemm_i8(int kind, const int8_t* A, int lda, int M, int K, int N, const p
   return run_gemm(kind, A, lda, M, K, N, *lin, *epi, out, ldo, out_codes, (hipStream_t)stream);
 }
 
+size_t p2v_resid_prefold_bytes(int N) { return N > 0 ? resid_tab_floats(N) * sizeof(float) : 0; }
+
+int p2v_resid_prefold(const p2v_linear* lin, const p2v_epilogue* epi, int N, float* tab, size_t tab_bytes, int* usable, void* stream) {
+  if (!lin || !epi || !tab || !usable) return fail(P2V_E_ARG, "p2v_resid_prefold: null argument");
+  *usable = 0;
+  if (N <= 0) return fail(P2V_E_SHAPE, "p2v_resid_prefold: N must be positive");
+  if (!lin->colscale || !lin->bias || !epi->s_mid || !epi->s_res || !epi->s_next) return fail(P2V_E_ARG, "p2v_resid_prefold: needs colscale / bias / s_mid / s_res / s_next");
+  if (tab_bytes < p2v_resid_prefold_bytes(N)) return fail(P2V_E_WORKSPACE, "p2v_resid_prefold: table %zu < %zu bytes", tab_bytes, p2v_resid_prefold_bytes(N));
+  OwnerDevice dev(tab);
+  if (!dev.ok()) return fail(P2V_E_ARG, "p2v_resid_prefold: tab is not a device pointer");
+  return resid_prefold_impl(*lin, *epi, N, tab, usable, (hipStream_t)stream);
+}
+
 int p2v_int_layernorm(const int8_t* x, long long row_stride, int rows, int C, const p2v_ln* ln, int8_t* out, long long out_stride,
                       void* stream) {
   if (!x || !ln || !out) return fail(P2V_E_ARG, "p2v_int_layernorm: null argument");
@@ -669,6 +784,8 @@ int p2v_window_attention(const int8_t* qkv, int batch, int tokens_per_image, int
       (wa->out_stride && wa->out_stride < heads * head_dim))
     return fail(P2V_E_SHAPE, "window attention: row strides must cover a row and be 16 / 4 byte aligned");
   if (wa->s_q2 > 1.0f) return fail(P2V_E_UNSUPPORTED, "window attention: qact2 scale above 1 (the -100 mask would not be an integer)");
+  if (wa->s_q1 / wa->s_q3 > 0x1p15f || wa->s_q1 / wa->s_q3 < 0x1p-40f)
+    return fail(P2V_E_UNSUPPORTED, "window attention: qact1 scale / qact3 scale must lie in [2^-40, 2^15]");
   WinAttnArgs a{qkv, batch, tokens_per_image, heads, *wa, out, probs_k};
   return launch_rc(p2v_launch_window_attention(a, (hipStream_t)stream), "window_attention");
 }

@@ -244,6 +244,27 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 typedef short v2i16 __attribute__((ext_vector_type(2)));
 
+// Activation outputs are written once and read by the NEXT kernel, tens of MB later: stored with the non-temporal hint so that their lines
+// do not push the operands a GEMM's neighbouring tiles share (the weight slabs, the activation panel) out of the XCD's L2
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+#ifndef P2V_NT_STORES
+#define P2V_NT_STORES 1
+#endif
+__device__ __forceinline__ void store_out16(void* p, uint4 v) {
+#if P2V_NT_STORES
+  __builtin_nontemporal_store((v4u){v.x, v.y, v.z, v.w}, reinterpret_cast<v4u*>(p));
+#else
+  *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void store_out4(void* p, unsigned v) {
+#if P2V_NT_STORES
+  __builtin_nontemporal_store(v, reinterpret_cast<unsigned*>(p));
+#else
+  *reinterpret_cast<unsigned*>(p) = v;
+#endif
+}
+
 #define CHECK_LAUNCH()                                     \
   do {                                                     \
     hipError_t e_ = hipGetLastError();                     \

@@ -15,6 +15,7 @@
 #define GBN 128
 #define GBK 64
 #define P2V_EPI_GELU_TAB 5   // internal: P2V_EPI_GELU with a threshold table in LDS (p2v_epilogue.gelu.table != NULL)
+#define P2V_EPI_RESID_PRE 6  // internal: P2V_EPI_RESID with the constants of p2v_resid_prefold (p2v_epilogue.resid_tab != NULL)
 
 __device__ __forceinline__ int lds_off64(int row, int chunk) { return row * GBK + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
@@ -108,7 +109,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
   if (EPI != P2V_EPI_HEAD) {
     uint4 o = halves_to_row16(d[0], d[1], d[2], d[3]);
     if (row_ok && n_tile + 16 * h < g.N)
-      *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + out_row * g.ldo + n_tile + 16 * h) = o;
+      store_out16(reinterpret_cast<int8_t*>(g.out) + out_row * g.ldo + n_tile + 16 * h, o);
   }
 }
 
@@ -206,7 +207,94 @@ __device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_
   for (int b = 0; b < 2; ++b) {
     const uint4 o = halves_to_row16(d[b][0], d[b][1], d[b][2], d[b][3]);
     if (row_ok[b] && n_tile + 16 * h < g.N)
-      *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)(m_first + 32 * b) * g.ldo + n_tile + 16 * h) = o;
+      store_out16(reinterpret_cast<int8_t*>(g.out) + (long long)(m_first + 32 * b) * g.ldo + n_tile + 16 * h, o);
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// RESID epilogue on pre-folded constants (p2v_resid_prefold, include/p2vit.h): QLinear -> QAct(PTF) -> + residual -> QAct(PTF)
+// (vit_fquant.py:334-338,431; layers_quant.py:342-346, vit_fquant.py:468).  Per output, after the accumulator:
+//   t  = fma(acc, colscale * fl(1/s_mid), bias * fl(1/s_mid))       the first quotient in one instruction; margin test as in div_q8fx4
+//                                                                     (one test per EIGHT outputs; the rare undecided lane divides exactly)
+//   q3 = clamp(rint(t));  xs = RN(res * s_res) + RN(q3 * s_mid)      the reference's three roundings
+//   q  = clamp(rint(fma(xs, rh, xs * rl)))                           second quotient by a 48-bit reciprocal, no test: every numerator
+//                                                                     this channel can produce was checked against the IEEE division
+//                                                                     when the table was built (k_resid_prefold)
+// 14 VALU instructions per output against 17.5 of the generic form, six instead of eight ds_read_b128 of constants per four channels,
+// and one wave-uniform branch per eight outputs instead of four.
+// ---------------------------------------------------------------------------------------------------
+#define P2V_RESID_TAB_ARRAYS 6
+struct ResidLds {
+  float c1[GBN], b1[GBN], s_mid[GBN], s_res[GBN], rh[GBN], rl[GBN];
+};
+// the second quotient exactly as the epilogue computes it (also used by the table builder's exhaustive check)
+__device__ __forceinline__ float resid_q2(float xs, float rh, float rl) { return __builtin_fmaf(xs, rh, xs * rl); }
+
+template <bool LEAN>
+__device__ __forceinline__ void gemm_epilogue_resid_pre(const v16i (&acc)[2], int m_first, int n_tile, int nl, int h, const GemmArgs& g,
+                                                        const ResidLds* e, const uint4 (&resv)[2]) {
+  unsigned d[2][4], res[2][4];
+  const bool row_ok[2] = {m_first < g.M, m_first + 32 < g.M};
+  row16_to_halves(resv[0], res[0][0], res[0][1], res[0][2], res[0][3]);
+  row16_to_halves(resv[1], res[1][0], res[1][1], res[1][2], res[1][3]);
+  struct Consts { float4 c1, b1, sm, sr, rh, rl; };
+  auto load_consts = [&](int gq) {
+    const int c = nl + 8 * gq + 4 * h;
+    Consts k;
+    k.c1 = *reinterpret_cast<const float4*>(e->c1 + c); k.b1 = *reinterpret_cast<const float4*>(e->b1 + c);
+    k.sm = *reinterpret_cast<const float4*>(e->s_mid + c); k.sr = *reinterpret_cast<const float4*>(e->s_res + c);
+    k.rh = *reinterpret_cast<const float4*>(e->rh + c); k.rl = *reinterpret_cast<const float4*>(e->rl + c);
+    return k;
+  };
+  Consts knext;
+  if (!LEAN) knext = load_consts(0);
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const Consts k = LEAN ? load_consts(gq) : knext;
+    if (!LEAN && gq < 3) knext = load_consts(gq + 1);     // an LDS round trip ahead of its use
+    const float c1[4] = {k.c1.x, k.c1.y, k.c1.z, k.c1.w}, b1[4] = {k.b1.x, k.b1.y, k.b1.z, k.b1.w};
+    const float sm[4] = {k.sm.x, k.sm.y, k.sm.z, k.sm.w}, sr[4] = {k.sr.x, k.sr.y, k.sr.z, k.sr.w};
+    const float rh[4] = {k.rh.x, k.rh.y, k.rh.z, k.rh.w}, rl[4] = {k.rl.x, k.rl.y, k.rl.z, k.rl.w};
+    float r[2][4], dv[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float t = __builtin_fmaf((float)acc[b][4 * gq + i], c1[i], b1[i]);
+        r[b][i] = rintf(t);
+        dv[b][i] = t - r[b][i];
+      }
+    const float dmax = fmaxf(fmaxf(fmaxf(fmaxf(fabsf(dv[0][0]), fabsf(dv[0][1])), fabsf(dv[0][2])), fmaxf(fabsf(dv[0][3]), fabsf(dv[1][0]))),
+                             fmaxf(fmaxf(fabsf(dv[1][1]), fabsf(dv[1][2])), fabsf(dv[1][3])));
+    if (__builtin_amdgcn_ballot_w64(!(dmax < 0.5f - 1.0e-4f)) != 0) {      // ~1e-3 of the waves: the reference's own operations for the undecided lanes
+      const int n = n_tile + 8 * gq + 4 * h;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (!(fabsf(dv[b][i]) < 0.5f - 1.0e-4f) && n + i < g.N) {
+            const float y = __builtin_fmaf((float)acc[b][4 * gq + i], g.colscale[n + i] * (g.w4 ? 0.0625f : 1.0f), g.bias[n + i]);
+            r[b][i] = rintf(y / g.ep.s_mid[n + i]);
+          }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float c[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float q3 = clamp8f(r[b][i]);
+        const float xs = (float)sx8(res[b][gq], i) * sr[i] + q3 * sm[i];
+        c[i] = pre_pack(resid_q2(xs, rh[i], rl[i]));
+      }
+      d[b][gq] = pack4_pre(c[0], c[1], c[2], c[3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the constant reads of the next group from being hoisted (register pressure)
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const uint4 o = halves_to_row16(d[b][0], d[b][1], d[b][2], d[b][3]);
+    if (row_ok[b] && n_tile + 16 * h < g.N)
+      store_out16(reinterpret_cast<int8_t*>(g.out) + (long long)(m_first + 32 * b) * g.ldo + n_tile + 16 * h, o);
+  }
+}

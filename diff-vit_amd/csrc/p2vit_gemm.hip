@@ -249,7 +249,8 @@ __global__ __launch_bounds__(128 * MT, MT == 4 ? 4 : 3) void k_gemm_dma(GemmArgs
   constexpr int TBM = 64 * MT;                                   // tile rows
   constexpr int NTH = 128 * MT;                                  // threads
   constexpr int STAGE = (TBM + GBN) * GBK;                       // X tile + W tile (a packed int4 W tile fills half of its 8 KB)
-  constexpr int EPI_BYTES = (EPI == P2V_EPI_RESID) ? (int)sizeof(EpiLds) : 2 * GBN * (int)sizeof(float);   // colscale + bias only
+  constexpr bool RES = EPI == P2V_EPI_RESID || EPI == P2V_EPI_RESID_PRE;
+  constexpr int EPI_BYTES = EPI == P2V_EPI_RESID ? (int)sizeof(EpiLds) : (EPI == P2V_EPI_RESID_PRE ? (int)sizeof(ResidLds) : 2 * GBN * (int)sizeof(float));   // else colscale + bias only
   __shared__ __attribute__((aligned(1024))) int8_t lds[NST * STAGE + EPI_BYTES];
   EpiLds* sE = reinterpret_cast<EpiLds*>(lds + NST * STAGE);
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];   // GELU threshold table (cells * 8 bytes)
@@ -316,7 +317,12 @@ __global__ __launch_bounds__(128 * MT, MT == 4 ? 4 : 3) void k_gemm_dma(GemmArgs
 
   // ---- epilogue constants / GELU table (compiler-visible LDS stores: they may wait for the requests above, which the first
   //      k-tile needs anyway); residual codes requested early
-  gemm_stage_epilogue<EPI>(sE, n0, tid, g);
+  if constexpr (EPI == P2V_EPI_RESID_PRE) {      // the tile's six pre-folded arrays: one contiguous 3 KB block of the table
+    if (tid < P2V_RESID_TAB_ARRAYS * GBN / 4)
+      reinterpret_cast<float4*>(sE)[tid] = reinterpret_cast<const float4*>(g.ep.resid_tab + (long long)tn * (P2V_RESID_TAB_ARRAYS * GBN))[tid];
+  } else {
+    gemm_stage_epilogue<EPI>(sE, n0, tid, g);
+  }
   if (EPI == P2V_EPI_GELU_TAB)
     for (int i = tid; i < g.ep.gelu.cells; i += NTH)
       reinterpret_cast<uint2*>(dyn_lds)[i] = reinterpret_cast<const uint2*>(g.ep.gelu.table)[i];
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(128 * MT, MT == 4 ? 4 : 3) void k_gemm_dma(GemmArgs
       if (m < g.M && n < g.N) resv[ni][mi] = *reinterpret_cast<const uint4*>(g.ep.residual + (long long)m * g.ldo + n);
     }
   };
-  if (EPI == P2V_EPI_RESID && MT == 2) {
+  if (RES && MT == 2) {
     load_resid(0);
     load_resid(1);
   }
@@ -376,9 +382,13 @@ __global__ __launch_bounds__(128 * MT, MT == 4 ? 4 : 3) void k_gemm_dma(GemmArgs
   GD_STAMP(3);
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
-    if (EPI == P2V_EPI_RESID && MT == 4) load_resid(ni);              // (held across the other group's epilogue they would spill)
-    gemm_epilogue_tile2<EPI, (MT == 4 && EPI == P2V_EPI_RESID)>(acc[ni], m0 + wm * 64 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, sE,
-                                                                 resv[ni], dyn_lds);
+    if (RES && MT == 4) load_resid(ni);                                // (held across the other group's epilogue they would spill)
+    if constexpr (EPI == P2V_EPI_RESID_PRE)
+      gemm_epilogue_resid_pre<MT == 4>(acc[ni], m0 + wm * 64 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g,
+                                       reinterpret_cast<const ResidLds*>(sE), resv[ni]);
+    else
+      gemm_epilogue_tile2<EPI, (MT == 4 && EPI == P2V_EPI_RESID)>(acc[ni], m0 + wm * 64 + l31, n0 + wn * 64 + ni * 32, wn * 64 + ni * 32, h, g, sE,
+                                                                   resv[ni], dyn_lds);
   }
   GD_STAMP(4);
 }
@@ -395,6 +405,7 @@ int p2v_launch_embed_fp32(const float* img, int B, int C, int H, int W, int P, c
   return 0;
 }
 
+int g_resid_pre = 1;      // P2V_RESID_PRE=0: ignore p2v_epilogue.resid_tab (A/B and parity runs of the generic RESID epilogue)
 int g_gemm_tile = 0;      // P2V_GEMM_TILE: 0 = by grid size, 128 / 256 = force the tile height of the layer GEMMs
 static int device_cus() {
   static int cus[16] = {0};
@@ -457,7 +468,10 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
         if (tab_bytes) hipLaunchKernelGGL(KERNEL(P2V_EPI_GELU_TAB), grid4, block4, tab_bytes, st, g);                     \
         else hipLaunchKernelGGL(KERNEL(P2V_EPI_GELU), grid4, block4, 0, st, g);                                           \
         break;                                                                                                            \
-      case P2V_EPI_RESID: hipLaunchKernelGGL(KERNEL(P2V_EPI_RESID), grid4, block4, 0, st, g); break;                      \
+      case P2V_EPI_RESID:                                                                                                 \
+        if (g.ep.resid_tab && g_resid_pre) hipLaunchKernelGGL(KERNEL(P2V_EPI_RESID_PRE), grid4, block4, 0, st, g);        \
+        else hipLaunchKernelGGL(KERNEL(P2V_EPI_RESID), grid4, block4, 0, st, g);                                          \
+        break;                                                                                                            \
       default: return -1;                                                                                                 \
     }
 #define P2V_K_DMA3(E) (k_gemm_dma<E, false, 2>)
@@ -487,3 +501,62 @@ int p2v_launch_gemm(int epi, const GemmArgs& g0, hipStream_t st) {
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Table builder of the pre-folded RESID epilogue (p2v_resid_prefold): one workgroup per output channel.  Writes the channel's six
+// constants and runs the exhaustive check of the test-free second quotient: all 256 x 256 (residual code, q3 code) numerators through
+// the reference's own operations (three roundings, IEEE division, round-half-even, clamp) and through the epilogue's form.
+// flags[0] &= every channel usable;  flags[1] += mismatching numerators (diagnostic).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resid_prefold(const float* __restrict__ colscale, const float* __restrict__ bias, int w4,
+                                                       const float* __restrict__ s_mid, const float* __restrict__ s_res,
+                                                       const float* __restrict__ s_next, int N, float* __restrict__ tab, unsigned* flags) {
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float* t6 = tab + (long long)(n / GBN) * (P2V_RESID_TAB_ARRAYS * GBN) + (n % GBN);
+  if (n >= N) {                              // padding columns of the last tile: harmless values, never stored
+    if (tid == 0) { t6[0] = 0.f; t6[GBN] = 0.f; t6[2 * GBN] = 1.f; t6[3 * GBN] = 1.f; t6[4 * GBN] = 1.f; t6[5 * GBN] = 0.f; }
+    return;
+  }
+  const float cs = colscale[n] * (w4 ? 0.0625f : 1.0f), bs = bias[n], sm = s_mid[n], sr = s_res[n], sn = s_next[n];
+  const float rm = 1.0f / sm;
+  const float rh = 1.0f / sn;
+  const float rl = (float)(1.0 / (double)sn - (double)rh);
+  bool ok = sm > 0.f && sr > 0.f && sn > 0.f && sm < 1.0e30f && sr < 1.0e30f && sn < 1.0e30f && sm > 1.0e-30f && sr > 1.0e-30f && sn > 1.0e-30f;
+  {   // (i) the folded first quotient: colscale a power of two well inside the normal range (its product with fl(1/s_mid) is then exact)
+      //     and |bias / s_mid| <= 512 (error bound of the folded form, include/p2vit.h)
+    const unsigned cb = __float_as_uint(cs);
+    ok = ok && (cb & 0x807FFFFFu) == 0u && (cb >> 23) - 32u <= 190u && fabsf(bs * rm) <= 512.f;
+  }
+  unsigned bad = 0;
+  if (ok) {
+    const float q3 = (float)(tid - 128);
+    const float a = q3 * sm;
+#pragma unroll 4
+    for (int rc = -128; rc < 128; ++rc) {
+      const float xs = (float)rc * sr + a;
+      const float ref = clamp8f(rintf(xs / sn));                                                    // the reference: IEEE division
+      const float c = pre_pack(resid_q2(xs, rh, rl));
+      const int got = sx8(pack4_pre(c, c, c, c), 0);                                                // the epilogue: bytes as packed
+      bad += (int)ref != got ? 1u : 0u;
+    }
+  }
+  __shared__ unsigned s_bad;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  if (bad) atomicAdd(&s_bad, bad);
+  __syncthreads();
+  if (tid == 0) {
+    if (!ok || s_bad) atomicAnd(&flags[0], 0u);
+    if (s_bad) atomicAdd(&flags[1], s_bad);
+    t6[0] = cs * rm; t6[GBN] = bs * rm; t6[2 * GBN] = sm; t6[3 * GBN] = sr; t6[4 * GBN] = rh; t6[5 * GBN] = rl;
+  }
+}
+
+// flags: dev [2], preset by the caller to {1, 0}
+int p2v_launch_resid_prefold(const p2v_linear& lin, const p2v_epilogue& ep, int N, float* tab, unsigned* flags, hipStream_t st) {
+  const int n_pad = (N + GBN - 1) / GBN * GBN;
+  hipLaunchKernelGGL(k_resid_prefold, dim3(n_pad), dim3(256), 0, st, lin.colscale, lin.bias, lin.packed4 ? 1 : 0, ep.s_mid, ep.s_res, ep.s_next, N, tab,
+                     flags);
+  CHECK_LAUNCH();
+  return 0;
+}

@@ -76,6 +76,8 @@ int p2v_launch_fill_cls(int8_t* x, int B, int T, int D, const int8_t* cls, hipSt
 // fp32 image x fake-quantised conv weights (input_quant = False): EMBED epilogue, g.A unused, g.W unpacked int8 codes [n_pad][K]
 int p2v_launch_embed_fp32(const float* img, int B, int C, int H, int W, int P, const GemmArgs& g, hipStream_t st);
 int p2v_launch_gemm(int epi, const GemmArgs& g, hipStream_t st);
+// table of the pre-folded RESID epilogue (p2v_epilogue.resid_tab): [ceil(N/128)][6][128] floats; flags: dev [2] preset to {1, 0}
+int p2v_launch_resid_prefold(const p2v_linear& lin, const p2v_epilogue& ep, int N, float* tab, unsigned* flags, hipStream_t st);
 int p2v_launch_layernorm(const LnArgs& a, hipStream_t st);
 bool p2v_ln_gemm_supported(int epi, int C, int N, int table_cells);
 int p2v_launch_ln_gemm(int epi, const LnArgs& a, const GemmArgs& g, hipStream_t st);   // -3: shape not fused

@@ -47,12 +47,17 @@ __device__ __forceinline__ float ln_elem_generic(float xq, float g, float bta, f
 // LDSC: post_mul and the PTF mask are re-read from the workgroup's LDS copy where they are used (one ds_read_b128 per four channels and
 // row) instead of living in 8 * NCH registers - the stand-alone kernel, whose scratch stays valid, then fits two rows per batch (ln_rows)
 // in the register budget of three waves per SIMD
+// The lane-resident PTF mask is kept TIMES 2^-16 (LN_XS), so x_q = code * mask arrives scaled by 2^-16 for free: the fast chain multiplies it by
+// T * 2^16 (below), the partial sums are scaled back once per lane and row (powers of two: every product, sum and rounding is unchanged).
+#define LN_XS 0x1p-16f
+#define LN_XS_INV 65536.f
+__device__ __forceinline__ float4 ln_scale_mask(float4 m) { return make_float4(m.x * LN_XS, m.y * LN_XS, m.z * LN_XS, m.w * LN_XS); }
 template <int NCH, bool LDSC = false>
 struct LnLane {
   bool on[NCH];
   float4 gm[NCH], bt[NCH];            // gamma*io, beta*io
   float4 pm[LDSC ? 1 : NCH];          // post_mul
-  float4 mkf[LDSC ? 1 : NCH];         // PTF mask (in_scale / s1): 1, 2, 4 or 8
+  float4 mkf[LDSC ? 1 : NCH];         // PTF mask (in_scale / s1): 1, 2, 4 or 8 - times LN_XS
   const float* sPl;                   // LDSC: this lane's first four channels in the LDS copies, and the chunk stride in floats
   const float* sMl;
   int cstride;
@@ -99,7 +104,7 @@ __device__ __forceinline__ void ln_prepare(const p2v_ln& ln, int C, bool force_g
     *reinterpret_cast<float4*>(sG + c) = make_float4(go[0], go[1], go[2], go[3]);
     *reinterpret_cast<float4*>(sB + c) = make_float4(bo[0], bo[1], bo[2], bo[3]);
     *reinterpret_cast<float4*>(sP + c) = pmv;
-    *reinterpret_cast<float4*>(sM + c) = mk;
+    *reinterpret_cast<float4*>(sM + c) = ln_scale_mask(mk);
   }
   L.pot = __syncthreads_and(potf) != 0;
   L.pm_one = __syncthreads_and(pm1) != 0;
@@ -154,7 +159,8 @@ template <int NCH, class LL>
 __device__ __forceinline__ void ln_sums(const unsigned (&wcur)[NCH], const LL& L, float (&xq)[NCH][4], int& S1, unsigned& S2) {
   S2 = 0;                                       // C * (128*8)^2 <= 2^31 for C <= 2048: exact in 32 unsigned bits
   // the lane's partial sums in fp32: |x_q| <= 1024, so sum x_q of 32 values and sum x_q^2 of 16 values (<= 2^24) are exact - full-rate
-  // add / fma instead of 24-bit multiplies and three-operand adds (profiles/r03_op_cost.txt); the cross-lane sums stay integers
+  // add / fma instead of 24-bit multiplies and three-operand adds (profiles/r03_op_cost.txt); the cross-lane sums stay integers.
+  // xq[][] holds x_q * 2^-16 (the mask is stored scaled, LN_XS): the sums come out times 2^-16 / 2^-32 and are scaled back per lane
   float S1p = 0.f, S2p = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -162,15 +168,15 @@ __device__ __forceinline__ void ln_sums(const unsigned (&wcur)[NCH], const LL& L
     const float4 mk_ = L.mask4(i);
     const float m4[4] = {mk_.x, mk_.y, mk_.z, mk_.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xq[i][j] = (float)sx8(w, j) * m4[j];       // x_q * in_scale_mask  (layers.py:269-273), exact; w == 0 past C
+    for (int j = 0; j < 4; ++j) xq[i][j] = (float)sx8(w, j) * m4[j];       // x_q * in_scale_mask  (layers.py:269-273) * 2^-16, exact; w == 0 past C
     S1p += (xq[i][0] + xq[i][1]) + (xq[i][2] + xq[i][3]);                  // (short dependency chains: a wave may be alone on its SIMD)
     S2p += __builtin_fmaf(xq[i][1], xq[i][1], xq[i][0] * xq[i][0]) + __builtin_fmaf(xq[i][3], xq[i][3], xq[i][2] * xq[i][2]);
     if ((i & 3) == 3 || i == NCH - 1) {
-      S2 += (unsigned)S2p;
+      S2 += (unsigned)(S2p * (LN_XS_INV * LN_XS_INV));
       S2p = 0.f;
     }
   }
-  S1 = (int)S1p;
+  S1 = (int)(S1p * LN_XS_INV);
 }
 template <int LANES>
 __device__ __forceinline__ void ln_reduce(int& S1, unsigned& S2) {
@@ -203,6 +209,10 @@ template <int NCH, int LANES, class LL>
 __device__ __forceinline__ void ln_apply(const float (&xq)[NCH][4], const LL& L, const p2v_ln& ln, int l32, float rs, float mos, bool fast,
                                          unsigned (&outw)[NCH]) {
   if (fast) {
+    // A2 = A * 2^16 (rs scaled once per row): sign * M * 2^-N * 2^16 = A2 with its low 16 mantissa bits cleared multiplies the SCALED x_q
+    // (xq[][] = x_q * 2^-16, LN_XS) - the same exact product as before; t = beta*io - mos*gamma*io is unchanged; and the magic constant of the
+    // offset rounding, 1.5 * 2^(23-N), has exactly A2's exponent field: ONE v_and_or_b32 (round 3: and + add of 16 to the field)
+    const float rs2 = rs * LN_XS_INV;
     auto chain = [&](auto PM1c) {
       constexpr bool PM1 = decltype(PM1c)::value;
 #pragma unroll
@@ -220,13 +230,16 @@ __device__ __forceinline__ void ln_apply(const float (&xq)[NCH][4], const LL& L,
           v2f T2, Bq2;
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            const float A = rs * g4[j + e];
+            const float A2 = rs2 * g4[j + e];                                       // A * 2^16 (exact scaling)
             const float t = b4[j + e] - mos * g4[j + e];
-            const unsigned Ab = __float_as_uint(A);
-            T2[e] = __uint_as_float(Ab & 0xFFFF0000u);                              // sign * M * 2^-N
-            // Bv * 2^-N = t rounded to the 2^-N grid, N = 134 - exp(A): C = 1.5 * 2^(23-N) has the exponent field exp(A) + 16 (4 full-rate
-            // instructions instead of bfe, add, sub, ldexp, rndne, ldexp: tools/ubench/op_cost.hip, profiles/r03_op_cost.txt)
-            const float Cm = __uint_as_float((Ab & 0x7F800000u) + 0x08400000u);
+            const unsigned Ab = __float_as_uint(A2);
+            T2[e] = __uint_as_float(Ab & 0xFFFF0000u);                              // sign * M * 2^-N * 2^16
+            // Bv * 2^-N = t rounded to the 2^-N grid, N = 134 - exp(A): C = 1.5 * 2^(23-N) has the exponent field exp(A) + 16 = exp(A2)
+            // (3 full-rate instructions instead of bfe, add, sub, ldexp, rndne, ldexp: tools/ubench/op_cost.hip, profiles/r03_op_cost.txt)
+            unsigned Cmb;       // (Ab & 0x7F800000) | 0x00400000 as ONE instruction (hipcc emits and + or: a VOP3 takes no literal, so the two
+                                // constants sit in a scalar and a vector register)
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(Cmb) : "v"(Ab), "s"(0x7F800000u), "v"(0x00400000u));
+            const float Cm = __uint_as_float(Cmb);
             Bq2[e] = (t + Cm) - Cm;
           }
           const v2f x2 = {xq[i][j], xq[i][j + 1]};
@@ -257,7 +270,7 @@ __device__ __forceinline__ void ln_apply(const float (&xq)[NCH][4], const LL& L,
       const float o4[4] = {ov.x, ov.y, ov.z, ov.w};
       float q[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q[j] = ln_elem_generic(xq[i][j], g4[j], b4[j], i4[j], p4[j], rs, mos, o4[j]);
+      for (int j = 0; j < 4; ++j) q[j] = ln_elem_generic(xq[i][j] * LN_XS_INV, g4[j], b4[j], i4[j], p4[j], rs, mos, o4[j]);
       outw[i] = pack4_sat(q[0], q[1], q[2], q[3]);
     }
   }
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
         mk = *reinterpret_cast<const float4*>(a.ln.mask + c);
       }
       *reinterpret_cast<float4*>(sP + c) = pmv;
-      *reinterpret_cast<float4*>(sM + c) = mk;
+      *reinterpret_cast<float4*>(sM + c) = ln_scale_mask(mk);
     }
     __syncthreads();
 #pragma unroll
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
       int8_t* dst = a.out + (row + u) * a.out_stride;
 #pragma unroll
       for (int i = 0; i < NCH; ++i)
-        if (L.on[i]) *reinterpret_cast<unsigned*>(dst + (l32 + LANES * i) * 4) = outw[u][i];
+        if (L.on[i]) store_out4(dst + (l32 + LANES * i) * 4, outw[u][i]);
     }
   }
 }
@@ -660,11 +673,15 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
     j = j < tiles_n ? j : tiles_n - 1;
     return wsrc + (long long)j * 4 * NI * 64;
   };
+  // at C = 384 the LayerNorm phase (48 registers of per-channel constants, two rows in flight) and a whole tile of W fragments (48) do not fit
+  // 256 registers together: hipcc spilled one fragment to scratch and reloaded it after the phase.  The LAST fragment of the first tile - used
+  // eleven k-steps after the phase ends - is therefore requested after the LayerNorm phase
+  constexpr int NI_EARLY = KT >= 6 ? NI - 1 : NI;
   wraw wf[NI];
   {
     const wraw* w0 = wtile(0);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wf[i] = w0[i * 64];
+    for (int i = 0; i < NI_EARLY; ++i) wf[i] = w0[i * 64];
   }
 
   // ---- the 64 rows of the residual stream: one row per half wave, 4 rows each, the second pair in flight while the first is normalised
@@ -722,7 +739,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
         L.gm[i] = *reinterpret_cast<const float4*>(a.pre.gm + c);
         L.bt[i] = *reinterpret_cast<const float4*>(a.pre.bt + c);
         L.pm[i] = L.on[i] ? *reinterpret_cast<const float4*>(a.ln.post_mul + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        L.mkf[i] = L.on[i] ? *reinterpret_cast<const float4*>(a.ln.mask + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        L.mkf[i] = L.on[i] ? ln_scale_mask(*reinterpret_cast<const float4*>(a.ln.mask + c)) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       L.gmin = a.pre.gmin;
       L.gmax = a.pre.gmax;
@@ -769,6 +786,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
     }
   }
   LG_STAMP(2);
+  if constexpr (NI_EARLY < NI) wf[NI - 1] = wtile(0)[(NI - 1) * 64];
   __syncthreads();        // panel, constants and table are complete
   LG_STAMP(3);
   if (n_g <= 0) return;   // wave-uniform (a layer with a single column tile: the second group has nothing to do)
@@ -910,7 +928,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
       const uint4 o = halves_to_row16(d[b][0], d[b][1], d[b][2], d[b][3]);
       const int m = m0 + 32 * b + l31;
       if (m < g.M && n_tile + 16 * h < g.N)
-        *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)m * g.ldo + n_tile + 16 * h) = o;
+        store_out16(reinterpret_cast<int8_t*>(g.out) + (long long)m * g.ldo + n_tile + 16 * h, o);
     }
     if constexpr (MF && COPY) {
       acc[0] = accn[0];

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libp2vit_hip.so')
 
-P2V_ABI_VERSION = 4
+P2V_ABI_VERSION = 5
 EPI_REQUANT, EPI_GELU, EPI_RESID, EPI_EMBED, EPI_HEAD = 0, 1, 2, 3, 4
 E_ARG, E_BITS, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH, E_STATE = -1, -2, -3, -4, -5, -6, -7
 
@@ -51,7 +51,7 @@ class GeluTab(C.Structure):
 class Epilogue(C.Structure):
     _fields_ = [('inv_s_out', _f), ('s_out', _f), ('s_mid', _p), ('s_res', _p), ('s_next', _p), ('residual', _p),
                 ('inv_s_pe', _f), ('pe_to_embed', _f), ('s_embed', _f), ('pos_deq', _p), ('patches', _i), ('gelu', GeluTab),
-                ('tap_out', _p)]
+                ('tap_out', _p), ('resid_tab', _p)]
 
 
 class Block(C.Structure):
@@ -99,6 +99,10 @@ def lib():
     L.p2v_plan_set_block.argtypes = [_p, _i, C.POINTER(Block)]
     L.p2v_plan_set_head.argtypes = [_p, C.POINTER(Ln), _f, _f]
     L.p2v_plan_block_prefolded.argtypes = [_p, _i]
+    L.p2v_plan_resid_prefolded.argtypes = [_p, _i]
+    L.p2v_resid_prefold_bytes.argtypes = [_i]
+    L.p2v_resid_prefold_bytes.restype = C.c_size_t
+    L.p2v_resid_prefold.argtypes = [C.POINTER(Linear), C.POINTER(Epilogue), _i, _p, C.c_size_t, C.POINTER(_i), _p]
     L.p2v_workspace_bytes.argtypes = [_p, _i]
     L.p2v_workspace_bytes.restype = C.c_size_t
     L.p2v_workspace_view.argtypes = [_p, _i, C.c_char_p]

@@ -150,7 +150,7 @@ class SwinPlan:
                                     E.ptr(b['reg']) if b['reg'] is not None else None, wsz, idx.shape[0])
                 b['proj'] = self._linear(p + 'attn.proj', s_q3)
                 s_b2 = c[p + 'qact2'].reshape(-1)
-                b['proj_epi'] = self._resid_epi(self._pot(p + 'attn.qact4'), s_res, s_b2, Cc)
+                b['proj_epi'] = self._resid_epi(self._pot(p + 'attn.qact4'), s_res, s_b2, Cc, b['proj'])
                 s3 = self._pot(p + 'qact3')
                 b['ln2'] = self._ln(p + 'norm2', s_b2, s3, Cc)
                 b['fc1'] = self._linear(p + 'mlp.fc1', s3, frag=Cc <= 384)
@@ -158,7 +158,7 @@ class SwinPlan:
                 b['inv_s_fc1'] = 1.0 / s_m1
                 b['fc2'] = self._linear(p + 'mlp.fc2', s_m1)
                 s_b4 = c[p + 'qact4'].reshape(-1)
-                b['fc2_epi'] = self._resid_epi(self._pot(p + 'mlp.qact2'), s_b2, s_b4, Cc)
+                b['fc2_epi'] = self._resid_epi(self._pot(p + 'mlp.qact2'), s_b2, s_b4, Cc, b['fc2'])
                 s_res = s_b4.clone()
                 blocks.append(b)
             st = dict(blocks=blocks, C=Cc, H=H, merge=None)
@@ -170,7 +170,7 @@ class SwinPlan:
                 # single PTF requant through the RESID epilogue: s_mid = s_next and an all-zero residual make it
                 # Q(Q(y; s) * s; s) = Q(y; s)   (|code * eps| << 0.5)
                 st['merge'] = dict(ln=self._ln(p + 'norm', s_res.repeat(4), sd1, 4 * Cc), red=red,
-                                   epi=self._resid_epi(sd2, torch.ones(2 * Cc), sd2, 2 * Cc))
+                                   epi=self._resid_epi(sd2, torch.ones(2 * Cc), sd2, 2 * Cc, red))
                 s_res = sd2.clone()
                 H //= 2
             self.stages.append(st)
@@ -182,10 +182,23 @@ class SwinPlan:
         self.head = self._linear('head', self.s_pool)
         self.s_out = self._pot('act_out')
 
-    def _resid_epi(self, s_mid, s_res, s_next, n):
+    def _resid_epi(self, s_mid, s_res, s_next, n, lin=None):
+        """constants of a RESID epilogue; with the layer's weights (``lin``) also the pre-folded table of ``p2v_resid_prefold`` - used
+        only when the library proves it gives the reference's codes for these constants (all 65 536 numerators of every channel)."""
         e = E.Epilogue()
         t = [self._vec(s_mid, n), self._vec(s_res, n), self._vec(s_next, n)]
         e.s_mid, e.s_res, e.s_next = [C.cast(E.ptr(x), C.c_void_p) for x in t]
+        if lin is not None:
+            L = E.lib()
+            nbytes = L.p2v_resid_prefold_bytes(n)
+            tab = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            usable = C.c_int(0)
+            torch.cuda.synchronize(self.device)                       # the vectors above were uploaded on torch's stream
+            E.check(L.p2v_resid_prefold(C.byref(lin['lin']), C.byref(e), n, E.ptr(tab), nbytes, C.byref(usable), None))
+            if usable.value:
+                self._keep.append(tab)
+                e.resid_tab = C.cast(E.ptr(tab), C.c_void_p)
+            self.resid_prefolded = getattr(self, 'resid_prefolded', []) + [bool(usable.value)]
         return e
 
     # ---- forward -------------------------------------------------------------------------------------------------------
@@ -237,7 +250,7 @@ class SwinPlan:
 
         def epi_res(src, residual):
             e = E.Epilogue()
-            e.s_mid, e.s_res, e.s_next, e.residual = src.s_mid, src.s_res, src.s_next, E.ptr(residual)
+            e.s_mid, e.s_res, e.s_next, e.residual, e.resid_tab = src.s_mid, src.s_res, src.s_next, E.ptr(residual), src.resid_tab
             return e
 
         o = E.Op()

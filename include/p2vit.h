@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define P2V_ABI_VERSION 4
+#define P2V_ABI_VERSION 5
 #define P2V_MAX_TOKENS 608   /* tokens per image of the ViT attention kernel (19 pairs of 32 keys) */
 
 enum {
@@ -150,7 +150,25 @@ typedef struct p2v_epilogue {
   float* tap_out;        /* REQUANT/GELU, optional: dev fp32 [M][N] receives the layer output BEFORE the
                             following QAct / GELU, acc*colscale + bias -- what the reference keeps as
                             Attention.qkv_output (vit_fquant.py:301) / Mlp.fc1_output (layers_quant.py:326) */
+  const float* resid_tab;/* RESID, optional (ABI 5): dev table written by p2v_resid_prefold for THIS (weights, epilogue) pair, or NULL.
+                            With it the launch runs the pre-folded epilogue (same codes, ~4 VALU instructions per output less); the
+                            frozen plan of p2v_forward builds and owns its tables itself */
 } p2v_epilogue;
+
+/* RESID epilogue constants folded ahead of the launches (round 4).  The reference computes, per output channel n (vit_fquant.py:334-338,431;
+ * layers_quant.py:342-346, vit_fquant.py:468),
+ *     q3 = clamp(round((acc * colscale[n] + bias[n]) / s_mid[n]));   q = clamp(round((res * s_res[n] + q3 * s_mid[n]) / s_next[n]))
+ * with two IEEE divisions by non-power-of-two PTF scales.  The table holds, per column tile of 128 channels, six arrays of 128 floats:
+ *     colscale * fl(1/s_mid), bias * fl(1/s_mid), s_mid, s_res, rh = fl(1/s_next), rl = fl(1/s_next - rh)
+ * (i)  the first quotient becomes ONE fma on the accumulator with the existing margin test (|t - rint t| < 0.5 - 1e-4, else the exact
+ *      division): valid when colscale is a power of two and |bias / s_mid| <= 512, which bounds the error of the folded form by 7e-5;
+ * (ii) the second quotient becomes xs * rh + xs * rl (a 48-bit reciprocal) WITHOUT a test: its numerator takes at most 65 536 values per
+ *      channel (256 residual codes x 256 q3 codes), and p2v_resid_prefold evaluates every one of them on the device against the IEEE
+ *      division - the table is usable only if all N x 65 536 results agree.
+ * *usable = 0 (table not to be used; the generic RESID epilogue gives the same codes) when (i) or (ii) does not hold.
+ * Synchronises `stream`.  tab: dev, p2v_resid_prefold_bytes(N) bytes, owned by the caller, must outlive the launches that use it. */
+size_t p2v_resid_prefold_bytes(int N);
+int p2v_resid_prefold(const p2v_linear* lin, const p2v_epilogue* epi, int N, float* tab, size_t tab_bytes, int* usable, void* stream);
 
 typedef struct p2v_plan p2v_plan;
 
@@ -191,9 +209,15 @@ typedef struct p2v_block {
  * returns P2V_OK - the kernels then fold per workgroup, with identical results - and leaves the reason in p2v_last_error();
  * p2v_plan_block_prefolded() tells which of the two a block got. */
 int p2v_plan_set_block(p2v_plan* plan, int block, const p2v_block* blk);
+/* (Round 4: p2v_plan_set_block and p2v_plan_set_linear also build the plan's RESID tables - p2v_resid_prefold for proj / fc2 of a block once
+ * both the block and the layer's weights are set; a later change of either rebuilds them.  blk->proj_epi.resid_tab / fc2_epi.resid_tab are
+ * ignored.) */
 /* 1: the LayerNorm constants of the block were folded when it was set; 0: its kernels fold per workgroup (p2v_last_error() of the
  * p2v_plan_set_block call says why); negative: error. */
 int p2v_plan_block_prefolded(const p2v_plan* plan, int block);
+/* which RESID tables of the block are in use: bit 0 proj / 4-bit weights, bit 1 proj / 8-bit, bit 2 fc2 / 4-bit, bit 3 fc2 / 8-bit
+ * (a clear bit of a layer whose weights are set: p2v_resid_prefold found the pre-folded form not provable, the generic epilogue runs). */
+int p2v_plan_resid_prefolded(const p2v_plan* plan, int block);
 
 int p2v_plan_set_head(p2v_plan* plan, const p2v_ln* final_ln, float inv_s_out, float s_out);
 

@@ -302,6 +302,118 @@ def test_gemm_residual_epilogue(dva, oracle):
     assert torch.equal(dev['xres'].cpu().float(), ref)
 
 
+def _resid_ref(oracle, x, w, s_x, s_w, bias, res, s_mid, s_res, s_next):
+    y = oracle.qgemm(x, torch.tensor(s_x), w, s_w, bias)
+    q3 = torch.clamp(torch.round(y / s_mid), -128, 127)                                     # IEEE divisions, as the reference (ptf.py:133)
+    return torch.clamp(torch.round((res * s_res + q3 * s_mid) / s_next), -128, 127)
+
+
+def _prefold(E, lin, epi, N):
+    L = E.lib()
+    nb = L.p2v_resid_prefold_bytes(N)
+    tab = torch.empty(nb // 4, dtype=torch.float32, device='cuda')
+    usable = C.c_int(-1)
+    E.check(L.p2v_resid_prefold(C.byref(lin), C.byref(epi), N, E.ptr(tab), nb, C.byref(usable), None))
+    return tab, usable.value
+
+
+@pytest.mark.parametrize('M,K,N,tile,w4', [(333, 256, 128, 128, False), (1000, 384, 384, 128, False), (777, 192, 208, 256, False),
+                                           (515, 1536, 384, 256, False), (394, 384, 384, 128, True), (300, 128, 256, 256, True)])
+def test_gemm_resid_prefold(dva, oracle, M, K, N, tile, w4):
+    """RESID epilogue on the constants of p2v_resid_prefold (round 4: the first quotient folded into the accumulator fma, the second by a
+    48-bit reciprocal without a test) against the oracle's IEEE divisions and against the generic epilogue, both tile heights, packed
+    int4 weights, ragged M, N not a multiple of the tile; PTF-style scales (base x {1,2,4,8}) and arbitrary per-channel scales."""
+    E, S = dva.engine, dva.synth
+    L = E.lib()
+    tag = 'pf%d_%d' % (M, N)
+    for variant in ('ptf', 'free'):
+        x = _rand_codes(S, 31, tag + 'x', (M, K)); w = _rand_codes(S, 31, tag + 'w', (N, K), 30.0)
+        if w4:
+            w = torch.clamp(torch.round(w / 16.0), -8, 7)
+        bias = S.normal(31, tag + 'b', (N,), 0.4)
+        res = _rand_codes(S, 31, tag + 'r', (M, N), 50.0)
+        if variant == 'ptf':
+            mk = lambda nm, base: base * 2.0 ** torch.floor(S.uniform(31, tag + nm, (N,), 0, 3.99))
+        else:
+            mk = lambda nm, base: base * S.uniform(31, tag + nm + 'f', (N,), 0.6, 7.9)
+        s_mid, s_res, s_next = mk('m', 0.0131), mk('r2', 0.0173), mk('n', 0.0209)
+        s_x = 2.0 ** -5
+        s_w = torch.full((N,), 2.0 ** (-4 if w4 else -8)) * (2.0 ** torch.floor(S.uniform(31, tag + 'sw', (N,), 0, 2.99)) if w4 else 1.0)
+        ref = _resid_ref(oracle, x, w, s_x, s_w, bias, res, s_mid, s_res, s_next)
+        n_pad = (N + 127) // 128 * 128
+        wp = torch.zeros(n_pad, K, dtype=torch.int8); wp[:N] = w.to(torch.int8)
+        pad = lambda v: torch.cat([v, torch.zeros(n_pad - N)]).cuda()
+        d = dict(x=x.to(torch.int8).cuda(), w=(E.pack_int4_tiles(wp) if w4 else wp).cuda(), cs=pad(s_x * s_w), b=pad(bias),
+                 sm=s_mid.cuda(), sr=s_res.cuda(), sn=s_next.cuda(), r=res.to(torch.int8).cuda())
+        lin = E.Linear(E.ptr(d['w']), E.ptr(d['cs']), E.ptr(d['b']), None, 1 if w4 else 0)
+        epi = E.Epilogue(); epi.s_mid = E.ptr(d['sm']); epi.s_res = E.ptr(d['sr']); epi.s_next = E.ptr(d['sn']); epi.residual = E.ptr(d['r'])
+        tab, usable = _prefold(E, lin, epi, N)
+        assert usable == 1, (variant, 'a random table failed the exhaustive check: expected about once in 1e5 channels')
+        assert L.p2v_set_tuning(b'gemm_tile', tile) == 0
+        try:
+            out_gen = torch.zeros(M, N, dtype=torch.int8, device='cuda')
+            E.check(L.p2v_gemm_i8(E.EPI_RESID, E.ptr(d['x']), K, M, K, N, C.byref(lin), C.byref(epi), E.ptr(out_gen), N, None, E.stream_ptr()))
+            epi.resid_tab = E.ptr(tab)
+            out_pre = torch.zeros(M, N, dtype=torch.int8, device='cuda')
+            E.check(L.p2v_gemm_i8(E.EPI_RESID, E.ptr(d['x']), K, M, K, N, C.byref(lin), C.byref(epi), E.ptr(out_pre), N, None, E.stream_ptr()))
+            assert L.p2v_set_tuning(b'resid_pre', 0) == 0            # the switch: the table is ignored
+            out_off = torch.zeros(M, N, dtype=torch.int8, device='cuda')
+            E.check(L.p2v_gemm_i8(E.EPI_RESID, E.ptr(d['x']), K, M, K, N, C.byref(lin), C.byref(epi), E.ptr(out_off), N, None, E.stream_ptr()))
+        finally:
+            L.p2v_set_tuning(b'gemm_tile', 0); L.p2v_set_tuning(b'resid_pre', 1)
+        assert torch.equal(out_gen.cpu().float(), ref), (variant, int((out_gen.cpu().float() != ref).sum()))
+        assert torch.equal(out_pre.cpu().float(), ref), (variant, int((out_pre.cpu().float() != ref).sum()))
+        assert torch.equal(out_off, out_gen)
+
+
+def test_gemm_resid_prefold_all_numerators(dva, oracle):
+    """every (residual code, q3 code) pair of every channel - the 65 536 numerators the second quotient can see - through the REAL
+    epilogue launch with pre-folded constants, against the oracle's IEEE arithmetic: the independent check of what p2v_resid_prefold
+    certifies on the device.  q3 is steered by the accumulator: w[n] = 2^f_n * [15, 1, 0...] with s_mid[n] = base * 2^f_n, so
+    y / s_mid = (15 a + b) * colscale / base for every channel."""
+    E, S = dva.engine, dva.synth
+    L = E.lib()
+    N, K = 128, 64
+    f = torch.floor(S.uniform(33, 'f', (N,), 0, 3.99))
+    base, cs = 0.0131, 2.0 ** -10
+    s_mid = base * 2.0 ** f
+    s_res = 0.0173 * 2.0 ** torch.floor(S.uniform(33, 'fr', (N,), 0, 3.99))
+    s_next = 0.0209 * S.uniform(33, 'fn', (N,), 0.7, 7.7)                   # arbitrary per-channel scales
+    q3 = torch.arange(-128, 128).float()
+    A = torch.round(q3 * base / cs)                                          # y / s_mid = A * cs / base = q3 +- 0.04
+    a = torch.round(A / 15.0); b = A - 15.0 * a
+    assert a.abs().max() <= 127 and b.abs().max() <= 127
+    x = torch.zeros(256 * 256, K); x[:, 0] = a.repeat_interleave(256); x[:, 1] = b.repeat_interleave(256)
+    res = torch.arange(-128, 128).float().repeat(256).reshape(-1, 1).expand(-1, N).contiguous()
+    w = torch.zeros(N, K); w[:, 0] = 15.0 * 2.0 ** f; w[:, 1] = 2.0 ** f
+    bias = torch.zeros(N)
+    ref = _resid_ref(oracle, x, w, 1.0, torch.full((N,), cs), bias, res, s_mid, s_res, s_next)
+    y = (x @ w.t()) * cs
+    assert torch.equal(torch.clamp(torch.round(y / s_mid), -128, 127)[::256, 0], q3)          # the steering works: all 256 q3 codes occur
+    d = dict(x=x.to(torch.int8).cuda(), w=w.to(torch.int8).cuda(), cs=torch.full((N,), cs).cuda(), b=bias.cuda(), sm=s_mid.cuda(),
+             sr=s_res.cuda(), sn=s_next.cuda(), r=res.to(torch.int8).cuda())
+    lin = E.Linear(E.ptr(d['w']), E.ptr(d['cs']), E.ptr(d['b']))
+    epi = E.Epilogue(); epi.s_mid = E.ptr(d['sm']); epi.s_res = E.ptr(d['sr']); epi.s_next = E.ptr(d['sn']); epi.residual = E.ptr(d['r'])
+    tab, usable = _prefold(E, lin, epi, N)
+    assert usable == 1
+    epi.resid_tab = E.ptr(tab)
+    out = torch.zeros(256 * 256, N, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_gemm_i8(E.EPI_RESID, E.ptr(d['x']), K, 256 * 256, K, N, C.byref(lin), C.byref(epi), E.ptr(out), N, None, E.stream_ptr()))
+    got = out.cpu().float()
+    assert torch.equal(got, ref), int((got != ref).sum())
+    # ... and what makes a table unusable: a bias beyond 512 output codes, a column scale that is not a power of two, bad arguments
+    big = bias.clone(); big[5] = 600.0 * float(s_mid[5])
+    d['b2'] = big.cuda()
+    lin2 = E.Linear(E.ptr(d['w']), E.ptr(d['cs']), E.ptr(d['b2']))
+    assert _prefold(E, lin2, epi, N)[1] == 0
+    d['cs2'] = (torch.full((N,), cs) * 1.01).cuda()
+    lin3 = E.Linear(E.ptr(d['w']), E.ptr(d['cs2']), E.ptr(d['b']))
+    assert _prefold(E, lin3, epi, N)[1] == 0
+    u = C.c_int(7)
+    assert L.p2v_resid_prefold(C.byref(lin), C.byref(epi), N, E.ptr(tab), 16, C.byref(u), None) == E.E_WORKSPACE and u.value == 0
+    assert L.p2v_resid_prefold(C.byref(lin), C.byref(epi), N, None, 1 << 20, C.byref(u), None) == E.E_ARG
+
+
 @pytest.mark.parametrize('C_,rows', [(64, 37), (192, 100), (384, 777), (768, 65), (1024, 9), (1536, 21), (2048, 35)])
 def test_int_layernorm(dva, oracle, C_, rows):
     E, S = dva.engine, dva.synth
@@ -770,6 +882,8 @@ def test_fp_input_model_engine_vs_reference_golden(dva, oracle, synth):
     L = dva.engine.lib()
     assert all(L.p2v_plan_block_prefolded(m._plan._handle, i) == 1 for i in range(a['depth']))
     assert L.p2v_plan_block_prefolded(m._plan._handle, a['depth']) < 0
+    # ... and so were the RESID tables of proj / fc2 for both weight widths (p2v_resid_prefold: provable for these constants)
+    assert all(L.p2v_plan_resid_prefolded(m._plan._handle, i) == 15 for i in range(a['depth']))
 
 
 def test_custom_ops_match_c_abi(dva, oracle, micro):
