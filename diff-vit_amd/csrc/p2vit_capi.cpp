@@ -139,6 +139,13 @@ static void read_env_once() {
 }
 int p2v_abi_version(void) { read_env_once(); return P2V_ABI_VERSION; }
 
+int p2v_max_tokens(int head_dim) {
+  if (head_dim == 32 || head_dim == 48 || head_dim == 64 || head_dim == 80) return P2V_MAX_TOKENS;
+  if (head_dim == 96) return 17 * 32;
+  if (head_dim == 128) return 12 * 32;
+  return 0;
+}
+
 int p2v_set_tuning(const char* name, int value) {
   if (!name) return fail(P2V_E_ARG, "p2v_set_tuning: null name");
   read_env_once();                      // an explicit setting wins over the environment
@@ -162,12 +169,18 @@ int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
   if (d.patch_size % 4) return fail(P2V_E_UNSUPPORTED, "patch_size must be a multiple of 4");
   if (d.embed_dim % d.num_heads) return fail(P2V_E_SHAPE, "embed_dim %% num_heads != 0");
   const int hd = d.embed_dim / d.num_heads;
-  if (hd != 32 && hd != 64) return fail(P2V_E_UNSUPPORTED, "head_dim %d (32 and 64 are instantiated)", hd);
-  if (d.embed_dim % 64 || d.mlp_hidden % 64) return fail(P2V_E_UNSUPPORTED, "embed_dim and mlp_hidden must be multiples of 64");
-  {   // the attention kernel keeps a query block's scores in registers and K / V^T of an image in LDS: up to 608 tokens (19 key pairs)
+  if (hd != 32 && hd != 48 && hd != 64 && hd != 80 && hd != 96 && hd != 128)
+    return fail(P2V_E_UNSUPPORTED, "head_dim %d (32, 48, 64, 80, 96 and 128 are instantiated)", hd);
+  // rows are read in 16-byte pieces and stored 16 channels at a time; widths that are not multiples of the 64-deep k-tile run through zero
+  // weight columns (the tile's last pieces then belong to the next row of the workspace buffer: multiplied by zero)
+  if (d.embed_dim % 16 || d.mlp_hidden % 16) return fail(P2V_E_UNSUPPORTED, "embed_dim and mlp_hidden must be multiples of 16");
+  {   // the attention kernel keeps a query block's scores in registers and K / V^T of an image's head in LDS (3 * head_dim bytes per key):
+      // 608 tokens (19 key pairs) up to head_dim 80, 544 at 96, 384 at 128
     const int tokens = (d.img_size / d.patch_size) * (d.img_size / d.patch_size) + 1;
-    if (tokens > P2V_MAX_TOKENS)
-      return fail(P2V_E_UNSUPPORTED, "%d tokens per image: the attention kernel covers up to %d (e.g. 384^2 / 16 = 577)", tokens, P2V_MAX_TOKENS);
+    const int max_tokens = p2v_max_tokens(hd);
+    if (tokens > max_tokens)
+      return fail(P2V_E_UNSUPPORTED, "%d tokens per image at head_dim %d: the attention kernel covers up to %d (e.g. 384^2 / 16 = 577 at head_dim <= 80)", tokens,
+                  hd, max_tokens);
   }
   if (d.embed_dim > 2048) return fail(P2V_E_UNSUPPORTED, "embed_dim %d: the LayerNorm kernel covers up to 2048 channels", d.embed_dim);
   p2v_plan* p = new p2v_plan();
@@ -436,7 +449,7 @@ static WsLayout ws_layout(const p2v_plan* p, int batch) {
   w.att = off;     off += al(M * D);
   w.hid = off;     off += al(M * (size_t)p->d.mlp_hidden);
   w.cls = off;     off += al((size_t)batch * D);
-  w.total = off;
+  w.total = off + 256;     // a k-tile of the last row of the last buffer may reach up to 48 bytes past the row (widths not a multiple of 64)
   return w;
 }
 
@@ -520,6 +533,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
          *bufHID = ws + w.hid, *bufCLS = ws + w.cls;
   const p2v_model_desc& d = p->d;
   const int D = d.embed_dim, T = p->tokens, M = batch * T, Hd = d.mlp_hidden, hd = D / d.num_heads;
+  const int Dk = round_up(D, GBK_PAD), Hk = round_up(Hd, GBK_PAD);     // contraction depths in whole k-tiles (weights are zero-padded to them)
   int launched = 0, rc;
   const bool taps = stop_after >= 0;      // parity runs read the workspace buffers: the fused kernels then also write the LayerNorm codes
 #define STEP(kind_, call)                             \
@@ -571,7 +585,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
       STEP(P2V_K_LN_GEMM_QKV, run_ln_gemm(P2V_EPI_REQUANT, ln, p->lin[bq][1 + 4 * i], e, 3 * D, bufQKV, st));
     } else {
       STEP(P2V_K_LAYERNORM, launch_rc(p2v_launch_layernorm(ln, st), "int_layernorm"));
-      STEP(P2V_K_GEMM_QKV, run_gemm(P2V_EPI_REQUANT, bufLN, D, M, D, 3 * D, p->lin[bq][1 + 4 * i], e, bufQKV, 3 * D, nullptr, st));
+      STEP(P2V_K_GEMM_QKV, run_gemm(P2V_EPI_REQUANT, bufLN, D, M, Dk, 3 * D, p->lin[bq][1 + 4 * i], e, bufQKV, 3 * D, nullptr, st));
     }
     // scores -> qact_attn1 -> log-int-softmax -> @v -> qact2                vit_fquant.py:309-326
     AttnArgs at{bufQKV, batch, T, d.num_heads, b.attn, bufATT, nullptr};
@@ -580,7 +594,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     p2v_epilogue ep = b.proj_epi;
     ep.residual = bufX;
     ep.resid_tab = p->resid_tab[(size_t)i * 4 + bp];
-    STEP(P2V_K_GEMM_PROJ, run_gemm(P2V_EPI_RESID, bufATT, D, M, D, D, p->lin[bp][2 + 4 * i], ep, bufX, D, nullptr, st));
+    STEP(P2V_K_GEMM_PROJ, run_gemm(P2V_EPI_RESID, bufATT, D, M, Dk, D, p->lin[bp][2 + 4 * i], ep, bufX, D, nullptr, st));
     // norm2 (attention's channel scale!) -> /mlp.channel_scale -> mlp.qact0 vit_fquant.py:464, layers_quant.py:305-311
     LnArgs ln2{bufX, D, M, D, b.ln2[bq][b1], bufLN, D};
     ln2.pre = p->ln_pre[(size_t)i * 6 + 2 + 2 * bq + b1];
@@ -594,13 +608,13 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
       STEP(P2V_K_LN_GEMM_FC1, run_ln_gemm(P2V_EPI_GELU, ln2, p->lin[b1][3 + 4 * i], e1, Hd, bufHID, st));
     } else {
       STEP(P2V_K_LAYERNORM, launch_rc(p2v_launch_layernorm(ln2, st), "int_layernorm"));
-      STEP(P2V_K_GEMM_FC1, run_gemm(P2V_EPI_GELU, bufLN, D, M, D, Hd, p->lin[b1][3 + 4 * i], e1, bufHID, Hd, nullptr, st));
+      STEP(P2V_K_GEMM_FC1, run_gemm(P2V_EPI_GELU, bufLN, D, M, Dk, Hd, p->lin[b1][3 + 4 * i], e1, bufHID, Hd, nullptr, st));
     }
     // fc2 -> qact2 -> + x -> Block.qact4                                    layers_quant.py:342-346, vit_fquant.py:468
     p2v_epilogue e2 = b.fc2_epi;
     e2.residual = bufX;
     e2.resid_tab = p->resid_tab[(size_t)i * 4 + 2 + b2];
-    STEP(P2V_K_GEMM_FC2, run_gemm(P2V_EPI_RESID, bufHID, Hd, M, Hd, D, p->lin[b2][4 + 4 * i], e2, bufX, D, nullptr, st));
+    STEP(P2V_K_GEMM_FC2, run_gemm(P2V_EPI_RESID, bufHID, Hd, M, Hk, D, p->lin[b2][4 + 4 * i], e2, bufX, D, nullptr, st));
   }
   // norm over the cls rows only ([:,0]) -> qact2 -> head -> act_out         vit_fquant.py:766-796
   LnArgs lf{bufX, (long long)T * D, batch, D, p->final_ln, bufCLS, D};
@@ -608,7 +622,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
   p2v_epilogue eh{};
   eh.inv_s_out = p->head_inv_s;
   eh.s_out = p->head_s;
-  STEP(P2V_K_GEMM_HEAD, run_gemm(P2V_EPI_HEAD, bufCLS, D, batch, D, d.num_classes, p->lin[bit_index(bit_config[n_cfg - 1])][n_cfg - 1], eh, logits,
+  STEP(P2V_K_GEMM_HEAD, run_gemm(P2V_EPI_HEAD, bufCLS, D, batch, Dk, d.num_classes, p->lin[bit_index(bit_config[n_cfg - 1])][n_cfg - 1], eh, logits,
                 d.num_classes, nullptr, st));
 #undef STEP
   if (prof) hipEventRecord(prof->ev[prof->used++], st);

@@ -157,48 +157,53 @@ __device__ __forceinline__ void gelu_q8x4(const float (&y)[4], float inv_s, floa
 // ---------------------------------------------------------------------------------------------------
 // GELU -> PoT requant as an EXACT threshold table (p2v_gelu_tab, include/p2vit.h).
 //   code(y) = clamp(rne(RN32(gelu(y)) * 2^e)) is a step function of the fp32 pre-activation y with < 256 steps.  The y axis is
-//   cut into cells of width s/2 (k = 2/s, a power of two, so y*k is exact):  i = clamp(floor(fma(y, k, off)), 0, cells-1).
+//   cut into cells of width s/2 (k = 2/s, a power of two, so u = y*k is exact):  i = clamp(floor(u) + off, 0, cells-1).
 //   Steps of the monotone branch are >= s/1.13 apart, so a cell holds at most ONE step (the builder verifies this for every
 //   cell, also around the minimum of GELU at y = -0.7518 where a down- and an up-step can come close); the entry is
-//   { thr, lo | hi << 8 } and code = y >= thr ? hi : lo  (thr = +inf for a cell without a step).
-//   Epilogue cost per output: fma, med3, cvt, shift, one ds_read_b64, v_cmp, v_cndmask (SDWA: selects the byte AND packs it
-//   into the output dword) -- 6 VALU after the bias fma, against ~22 for the A&S polynomial + margin test.
+//   { thr * k, lo | hi << 8 } and code = u >= thr * k ? hi : lo  (thr = +inf for a cell without a step).
+//   Epilogue cost per output: the fma that forms u from the accumulator, cvt_flr, med3, shift-add, one ds_read_b64, v_cmp, v_cndmask
+//   (SDWA: selects the byte AND packs it into the output dword) -- 5 VALU after that fma, against ~22 for the A&S polynomial + margin test.
 //   The table is built on the device by an exhaustive sweep over EVERY finite fp32 in real-line order with the fp64 erfc
 //   (k_gelu_tab_sweep): nothing about monotonicity or step spacing is assumed, it is checked.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned gelu_tab_offset(float y, float k, float off, float tmax) {
-  const float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(y, k, off), 0.f, tmax);    // y*k exact; NaN -> cell 0
-  return (unsigned)t << 3;                                                          // v_cvt_u32_f32 truncates: floor for t >= 0
+// u = y * k (exact: k is a power of two).  The epilogues get u straight from the accumulator - fma(acc, colscale * k, bias * k) IS
+// RN(acc * colscale + bias) * k - and never form y itself (round 4: one instruction per output less); cell = clamp(floor(u) + off), the
+// thresholds are stored times k.  Returns the byte offset of the entry RELATIVE TO ENTRY `off` (the callers fold off * 8 into the base);
+// lo = -off, hi = cells - 1 - off as floats: u is clamped to [lo, hi + 0.5] first (one v_med3_f32; a NaN becomes lo), then floored.
+__device__ __forceinline__ int gelu_tab_offset(float u, float lo, float hi_half) {
+  int f;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(f) : "v"(__builtin_amdgcn_fmed3f(u, lo, hi_half)));
+  return f << 3;
 }
 __device__ __forceinline__ int gelu_code_exact(float y, float inv_s) {
   const float r = rintf(gelu_exact(y) * inv_s);
   return (int)clamp8f(r);
 }
-// byte B of d := (y >= thr) ? hi : lo   with e = {thr bits, lo | hi << 8}; the other bytes of d are kept (B > 0) / zeroed (B = 0)
+// byte B of d := (u >= thr) ? hi : lo   with e = {bits of thr * k, lo | hi << 8}; the other bytes of d are kept (B > 0) / zeroed (B = 0)
 #define P2V_GELU_SEL(B, UNUSED, DST, YV, ENT)                                                                             \
   asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:BYTE_" #B " dst_unused:" UNUSED              \
       " src0_sel:BYTE_0 src1_sel:BYTE_1"                                                                                   \
       : "+v"(DST) : "v"(YV), "v"(__uint_as_float(ENT.x)), "v"(ENT.y) : "vcc")
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 // eight outputs of one lane (two groups of four) -> two dwords of int8 codes: all eight table reads are requested before the first
-// select waits for one
-__device__ __forceinline__ void gelu_tab_q8x8(const float (&y0)[4], const float (&y1)[4], const unsigned char* tab, float k, float off, float tmax,
+// select waits for one.  u0 / u1: the scaled pre-activations y * k;  tabz: entry `off` of the table (cell of u in [0, 1))
+__device__ __forceinline__ void gelu_tab_q8x8(const float (&u0)[4], const float (&u1)[4], const unsigned char* tabz, float lo, float hi,
                                               unsigned& d0, unsigned& d1) {
   uint2 e0[4], e1[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) e0[i] = *reinterpret_cast<const uint2*>(tab + gelu_tab_offset(y0[i], k, off, tmax));
+  for (int i = 0; i < 4; ++i) e0[i] = *reinterpret_cast<const uint2*>(tabz + gelu_tab_offset(u0[i], lo, hi));
 #pragma unroll
-  for (int i = 0; i < 4; ++i) e1[i] = *reinterpret_cast<const uint2*>(tab + gelu_tab_offset(y1[i], k, off, tmax));
+  for (int i = 0; i < 4; ++i) e1[i] = *reinterpret_cast<const uint2*>(tabz + gelu_tab_offset(u1[i], lo, hi));
   d0 = 0;
   d1 = 0;
-  P2V_GELU_SEL(0, "UNUSED_PAD", d0, y0[0], e0[0]);
-  P2V_GELU_SEL(1, "UNUSED_PRESERVE", d0, y0[1], e0[1]);
-  P2V_GELU_SEL(2, "UNUSED_PRESERVE", d0, y0[2], e0[2]);
-  P2V_GELU_SEL(3, "UNUSED_PRESERVE", d0, y0[3], e0[3]);
-  P2V_GELU_SEL(0, "UNUSED_PAD", d1, y1[0], e1[0]);
-  P2V_GELU_SEL(1, "UNUSED_PRESERVE", d1, y1[1], e1[1]);
-  P2V_GELU_SEL(2, "UNUSED_PRESERVE", d1, y1[2], e1[2]);
-  P2V_GELU_SEL(3, "UNUSED_PRESERVE", d1, y1[3], e1[3]);
+  P2V_GELU_SEL(0, "UNUSED_PAD", d0, u0[0], e0[0]);
+  P2V_GELU_SEL(1, "UNUSED_PRESERVE", d0, u0[1], e0[1]);
+  P2V_GELU_SEL(2, "UNUSED_PRESERVE", d0, u0[2], e0[2]);
+  P2V_GELU_SEL(3, "UNUSED_PRESERVE", d0, u0[3], e0[3]);
+  P2V_GELU_SEL(0, "UNUSED_PAD", d1, u1[0], e1[0]);
+  P2V_GELU_SEL(1, "UNUSED_PRESERVE", d1, u1[1], e1[1]);
+  P2V_GELU_SEL(2, "UNUSED_PRESERVE", d1, u1[2], e1[2]);
+  P2V_GELU_SEL(3, "UNUSED_PRESERVE", d1, u1[3], e1[3]);
 }
 
 // n-th finite fp32 in real-line order: n in [0, 2F), F = 0x7F800000 (negative values by falling magnitude, -0, +0, positives)
@@ -243,27 +248,6 @@ __device__ __forceinline__ void div_q8fx4(const float (&x)[4], const float (&s)[
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 typedef short v2i16 __attribute__((ext_vector_type(2)));
-
-// Activation outputs are written once and read by the NEXT kernel, tens of MB later: stored with the non-temporal hint so that their lines
-// do not push the operands a GEMM's neighbouring tiles share (the weight slabs, the activation panel) out of the XCD's L2
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-#ifndef P2V_NT_STORES
-#define P2V_NT_STORES 1
-#endif
-__device__ __forceinline__ void store_out16(void* p, uint4 v) {
-#if P2V_NT_STORES
-  __builtin_nontemporal_store((v4u){v.x, v.y, v.z, v.w}, reinterpret_cast<v4u*>(p));
-#else
-  *reinterpret_cast<uint4*>(p) = v;
-#endif
-}
-__device__ __forceinline__ void store_out4(void* p, unsigned v) {
-#if P2V_NT_STORES
-  __builtin_nontemporal_store(v, reinterpret_cast<unsigned*>(p));
-#else
-  *reinterpret_cast<unsigned*>(p) = v;
-#endif
-}
 
 #define CHECK_LAUNCH()                                     \
   do {                                                     \

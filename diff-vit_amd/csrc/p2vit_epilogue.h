@@ -30,7 +30,8 @@ __device__ __forceinline__ void gemm_stage_epilogue(EpiLds* e, int n0, int tid, 
     const int n = n0 + tid;
     // REQUANT: (acc*cs + b) * 2^e == acc*(cs*2^e) + b*2^e with the same single rounding (power-of-two scaling commutes with
     // rounding; the plan checks that 1/s_out is a power of two), so the multiply leaves the per-output chain
-    const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : 1.0f;
+    // GELU_TAB: the table is indexed and compared on u = y * k (k = 2 / s_out, a power of two), see gelu_tab_offset
+    const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : (EPI == P2V_EPI_GELU_TAB ? g.ep.gelu.k : 1.0f);
     e->colscale[tid] = g.colscale[n] * fold * (g.w4 ? 0.0625f : 1.0f);   // arrays are padded to n_pad; packed int4: acc = 16 x sum
     e->bias[tid] = g.bias[n] * fold;
     const bool ok = n < g.N;
@@ -109,7 +110,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const v16i& acc, int m, int n
   if (EPI != P2V_EPI_HEAD) {
     uint4 o = halves_to_row16(d[0], d[1], d[2], d[3]);
     if (row_ok && n_tile + 16 * h < g.N)
-      store_out16(reinterpret_cast<int8_t*>(g.out) + out_row * g.ldo + n_tile + 16 * h, o);
+      *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + out_row * g.ldo + n_tile + 16 * h) = o;
   }
 }
 
@@ -173,13 +174,14 @@ __device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_
       yy[b][2] = __builtin_fmaf((float)acc[b][4 * gq + 2], cs.z, bs.z);
       yy[b][3] = __builtin_fmaf((float)acc[b][4 * gq + 3], cs.w, bs.w);
       if (EPI != P2V_EPI_RESID && g.ep.tap_out && row_ok[b] && n < g.N) {
-        const float un = EPI == P2V_EPI_REQUANT ? 1.0f / g.ep.inv_s_out : 1.0f;
+        const float un = EPI == P2V_EPI_REQUANT ? 1.0f / g.ep.inv_s_out : (EPI == P2V_EPI_GELU_TAB ? 1.0f / g.ep.gelu.k : 1.0f);
         *reinterpret_cast<float4*>(g.ep.tap_out + (long long)(m_first + 32 * b) * g.N + n) =
             make_float4(yy[b][0] * un, yy[b][1] * un, yy[b][2] * un, yy[b][3] * un);
       }
     }
     if (EPI == P2V_EPI_GELU_TAB) {
-      gelu_tab_q8x8(yy[0], yy[1], gtab, g.ep.gelu.k, g.ep.gelu.off, (float)(g.ep.gelu.cells - 1), d[0][gq], d[1][gq]);
+      const int goff = (int)g.ep.gelu.off;
+      gelu_tab_q8x8(yy[0], yy[1], gtab + goff * 8, (float)-goff, (float)(g.ep.gelu.cells - 1 - goff) + 0.5f, d[0][gq], d[1][gq]);
       continue;
     }
 #pragma unroll
@@ -207,7 +209,7 @@ __device__ __forceinline__ void gemm_epilogue_tile2(const v16i (&acc)[2], int m_
   for (int b = 0; b < 2; ++b) {
     const uint4 o = halves_to_row16(d[b][0], d[b][1], d[b][2], d[b][3]);
     if (row_ok[b] && n_tile + 16 * h < g.N)
-      store_out16(reinterpret_cast<int8_t*>(g.out) + (long long)(m_first + 32 * b) * g.ldo + n_tile + 16 * h, o);
+      *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)(m_first + 32 * b) * g.ldo + n_tile + 16 * h) = o;
   }
 }
 
@@ -295,6 +297,6 @@ __device__ __forceinline__ void gemm_epilogue_resid_pre(const v16i (&acc)[2], in
   for (int b = 0; b < 2; ++b) {
     const uint4 o = halves_to_row16(d[b][0], d[b][1], d[b][2], d[b][3]);
     if (row_ok[b] && n_tile + 16 * h < g.N)
-      store_out16(reinterpret_cast<int8_t*>(g.out) + (long long)(m_first + 32 * b) * g.ldo + n_tile + 16 * h, o);
+      *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)(m_first + 32 * b) * g.ldo + n_tile + 16 * h) = o;
   }
 }

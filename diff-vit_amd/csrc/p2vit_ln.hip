@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
       int8_t* dst = a.out + (row + u) * a.out_stride;
 #pragma unroll
       for (int i = 0; i < NCH; ++i)
-        if (L.on[i]) store_out4(dst + (l32 + LANES * i) * 4, outw[u][i]);
+        if (L.on[i]) *reinterpret_cast<unsigned*>(dst + (l32 + LANES * i) * 4) = outw[u][i];
     }
   }
 }
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void k_ln_gemm(LnArgs a, GemmArgs g) {
   load_row(1, win[1]);
   // ---- per-column constants of the whole layer (REQUANT: 2^e folded in, see gemm_stage_epilogue) and the GELU table
   {
-    const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : 1.0f;
+    const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : (EPI == P2V_EPI_GELU_TAB ? g.ep.gelu.k : 1.0f);   // GELU_TAB: u = y * k, see gelu_tab_offset
     const float cfold = fold * (W4 ? 0.0625f : 1.0f);                   // packed int4: the accumulator holds 16 x the sum
     for (int n4 = tid; n4 < tiles_n * (GBN / 4); n4 += 256) {           // four columns per thread and turn
       const int j_ = n4 >> 5, c_ = (n4 & 31) * 4;
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
   for (int u = 0; u < LR; ++u) load_row(u, win[u]);
   // ---- per-column constants of the whole layer (REQUANT: 2^e folded in, see gemm_stage_epilogue) and the GELU table
   {
-    const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : 1.0f;
+    const float fold = EPI == P2V_EPI_REQUANT ? g.ep.inv_s_out : (EPI == P2V_EPI_GELU_TAB ? g.ep.gelu.k : 1.0f);   // GELU_TAB: u = y * k, see gelu_tab_offset
     const float cfold = fold * (W4 ? 0.0625f : 1.0f);                   // packed int4: the accumulator holds 16 x the sum
     for (int n4 = tid; n4 < tiles_n * (GBN / 4); n4 += NT) {           // four columns per thread and turn
       const int j_ = n4 >> 5, c_ = (n4 & 31) * 4;
@@ -821,7 +821,9 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
   XB[0] = *reinterpret_cast<const v4i*>(pXb + LG2_XOFF(0));
   XA[1] = XA[0];
   XB[1] = XB[0];
-  const float gk = g.ep.gelu.k, goff = g.ep.gelu.off, gtmax = (float)(cells - 1);
+  const int goff = (int)g.ep.gelu.off;
+  const float glo = (float)-goff, ghi = (float)(cells - 1 - goff) + 0.5f;     // clamp bounds of u ahead of the floor
+  const unsigned char* gtabz = gtab + goff * 8;                           // entry `off`: the cell of u in [0, 1)
 
   // One column tile: the epilogue of acc (tile j) in 24 half-pieces; with MF the 2*NI MFMAs of the group's next tile are issued
   // one per half-piece into accn (X fragments one k-step ahead); with LD the W fragment of the tile after next replaces the one
@@ -879,11 +881,11 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
         uint2 e0[4], e1[4];
         LG2_MFMA(6 * gq + 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) e0[i] = *reinterpret_cast<const uint2*>(gtab + gelu_tab_offset(y0[i], gk, goff, gtmax));
+        for (int i = 0; i < 4; ++i) e0[i] = *reinterpret_cast<const uint2*>(gtabz + gelu_tab_offset(y0[i], glo, ghi));
         LG2_FENCE();
         LG2_MFMA(6 * gq + 3);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) e1[i] = *reinterpret_cast<const uint2*>(gtab + gelu_tab_offset(y1[i], gk, goff, gtmax));
+        for (int i = 0; i < 4; ++i) e1[i] = *reinterpret_cast<const uint2*>(gtabz + gelu_tab_offset(y1[i], glo, ghi));
         LG2_FENCE();
         LG2_MFMA(6 * gq + 4);
         d[0][gq] = 0;
@@ -928,7 +930,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
       const uint4 o = halves_to_row16(d[b][0], d[b][1], d[b][2], d[b][3]);
       const int m = m0 + 32 * b + l31;
       if (m < g.M && n_tile + 16 * h < g.N)
-        store_out16(reinterpret_cast<int8_t*>(g.out) + (long long)m * g.ldo + n_tile + 16 * h, o);
+        *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(g.out) + (long long)m * g.ldo + n_tile + 16 * h) = o;
     }
     if constexpr (MF && COPY) {
       acc[0] = accn[0];

@@ -2,8 +2,13 @@
 // fake-quant helpers, Swin patch-merge gather and average pool; with their launchers.
 #include "p2vit_device.h"
 
-// scratch: cnt[cells] | thr[cells] | lohi[cells] | first[cells]; first[] preset to 0xFFFFFFFF, cnt[] to 0
-__global__ __launch_bounds__(256) void k_gelu_tab_sweep(float inv_s, float k, float off, float tmax, int cells, unsigned* scratch, int per_thread) {
+// cell of the pre-activation y: the epilogues' index function on u = y * k (gelu_tab_offset), as an entry number
+__device__ __forceinline__ unsigned gelu_tab_cell(float y, float k, int off, int cells) {
+  return (unsigned)((gelu_tab_offset(y * k, (float)-off, (float)(cells - 1 - off) + 0.5f) >> 3) + off);
+}
+// scratch: cnt[cells] | thr[cells] | lohi[cells] | first[cells]; first[] preset to 0xFFFFFFFF, cnt[] to 0.  thr[] receives the threshold
+// TIMES k (exact), the form the epilogues compare against
+__global__ __launch_bounds__(256) void k_gelu_tab_sweep(float inv_s, float k, int off, int cells, unsigned* scratch, int per_thread) {
   unsigned* cnt = scratch;
   unsigned* thr = scratch + cells;
   unsigned* lohi = scratch + 2 * cells;
@@ -15,18 +20,18 @@ __global__ __launch_bounds__(256) void k_gelu_tab_sweep(float inv_s, float k, fl
   if (n0 > 0) {
     const float yp = f32_in_order(n0 - 1);
     pc = gelu_code_exact(yp, inv_s);
-    pi = gelu_tab_offset(yp, k, off, tmax) >> 3;
+    pi = gelu_tab_cell(yp, k, off, cells);
   }
   for (int j = 0; j < per_thread; ++j) {
     const unsigned long long n = n0 + j;
     if (n >= 2 * P2V_F32_FINITE) break;
     const float y = f32_in_order(n);
     const int c = gelu_code_exact(y, inv_s);
-    const unsigned i = gelu_tab_offset(y, k, off, tmax) >> 3;
+    const unsigned i = gelu_tab_cell(y, k, off, cells);
     if (i != pi) first[i] = (unsigned)c & 255u;                 // first value of a cell: its code when the cell has no step
     if (n > 0 && c != pc) {
       atomicAdd(&cnt[i], 1u);
-      thr[i] = __float_as_uint(y);
+      thr[i] = __float_as_uint(y * k);
       lohi[i] = ((unsigned)pc & 255u) | (((unsigned)c & 255u) << 8);
     }
     pc = c;
@@ -43,7 +48,7 @@ __global__ void k_gelu_tab_finish(int cells, const unsigned* scratch, uint2* tab
   table[i] = c == 0 ? make_uint2(0x7F800000u, f | (f << 8)) : make_uint2(scratch[cells + i], scratch[2 * cells + i]);
 }
 // independent check: every finite fp32 through the epilogue's lookup against the fp64 evaluation
-__global__ __launch_bounds__(256) void k_gelu_tab_check(float inv_s, float k, float off, float tmax, const unsigned char* table,
+__global__ __launch_bounds__(256) void k_gelu_tab_check(float inv_s, float k, int off, int cells, const unsigned char* table,
                                                         unsigned long long* mismatches) {
   unsigned long long bad = 0;
   for (unsigned long long n = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * 8; n < 2 * P2V_F32_FINITE;
@@ -52,7 +57,10 @@ __global__ __launch_bounds__(256) void k_gelu_tab_check(float inv_s, float k, fl
 #pragma unroll
     for (int i = 0; i < 8; ++i) y[i >> 2][i & 3] = f32_in_order(n + i < 2 * P2V_F32_FINITE ? n + i : n);
     unsigned d[2];
-    gelu_tab_q8x8(y[0], y[1], table, k, off, tmax, d[0], d[1]);          // the lookup of the GEMM epilogues
+    float u[2][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i >> 2][i & 3] = y[i >> 2][i & 3] * k;
+    gelu_tab_q8x8(u[0], u[1], table + off * 8, (float)-off, (float)(cells - 1 - off) + 0.5f, d[0], d[1]);          // the lookup of the GEMM epilogues
 #pragma unroll
     for (int i = 0; i < 8; ++i) bad += (sx8(d[i >> 2], i & 3) != gelu_code_exact(y[i >> 2][i & 3], inv_s)) ? 1 : 0;
   }
@@ -234,7 +242,7 @@ int p2v_launch_gelu_table_build(float inv_s, const p2v_gelu_tab& t, unsigned* sc
   if (e != hipSuccess) return (int)e;
   const int per_thread = 2048;
   const unsigned long long threads = (2 * P2V_F32_FINITE + per_thread - 1) / per_thread;
-  hipLaunchKernelGGL(k_gelu_tab_sweep, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, inv_s, t.k, t.off, (float)(cells - 1), cells,
+  hipLaunchKernelGGL(k_gelu_tab_sweep, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, inv_s, t.k, (int)t.off, cells,
                      scratch, per_thread);
   CHECK_LAUNCH();
   hipLaunchKernelGGL(k_gelu_tab_finish, dim3((cells + 255) / 256), dim3(256), 0, st, cells, scratch,
@@ -244,7 +252,7 @@ int p2v_launch_gelu_table_build(float inv_s, const p2v_gelu_tab& t, unsigned* sc
 }
 
 int p2v_launch_gelu_table_check(float inv_s, const p2v_gelu_tab& t, unsigned long long* mismatches, hipStream_t st) {
-  hipLaunchKernelGGL(k_gelu_tab_check, dim3(8192), dim3(256), 0, st, inv_s, t.k, t.off, (float)(t.cells - 1),
+  hipLaunchKernelGGL(k_gelu_tab_check, dim3(8192), dim3(256), 0, st, inv_s, t.k, (int)t.off, t.cells,
                      reinterpret_cast<const unsigned char*>(t.table), mismatches);
   CHECK_LAUNCH();
   return 0;

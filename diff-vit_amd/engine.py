@@ -100,6 +100,7 @@ def lib():
     L.p2v_plan_set_head.argtypes = [_p, C.POINTER(Ln), _f, _f]
     L.p2v_plan_block_prefolded.argtypes = [_p, _i]
     L.p2v_plan_resid_prefolded.argtypes = [_p, _i]
+    L.p2v_max_tokens.argtypes = [_i]
     L.p2v_resid_prefold_bytes.argtypes = [_i]
     L.p2v_resid_prefold_bytes.restype = C.c_size_t
     L.p2v_resid_prefold.argtypes = [C.POINTER(Linear), C.POINTER(Epilogue), _i, _p, C.c_size_t, C.POINTER(_i), _p]

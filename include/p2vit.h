@@ -20,8 +20,12 @@
  *     per-channel PTF scales (ptf.py:51,133) are arbitrary fp32 and are divided by, as the reference does.
  *
  * Limits of what is instantiated (everything else returns P2V_E_UNSUPPORTED, at plan creation where the geometry is known):
- *   - ViT attention: head_dim 32 or 64; up to P2V_MAX_TOKENS = 608 tokens per image (224^2 / 16 = 197, 384^2 / 16 = 577, ...);
+ *   - ViT attention: head_dim 32, 48, 64, 80, 96 or 128 (round 4; before: 32 / 64); up to P2V_MAX_TOKENS = 608 tokens per image
+ *     (224^2 / 16 = 197, 384^2 / 16 = 577, ...) - 544 at head_dim 96 and 384 at head_dim 128, where K / V^T of an image's head fill the LDS:
+ *     p2v_max_tokens(head_dim);
  *     Swin window attention: head_dim 32, windows up to 8 x 8;
+ *   - embed_dim and MLP width of a plan: multiples of 16 (round 4; before: 64) - the contractions walk 64-deep k-tiles through zero weight
+ *     columns (p2v_linear: k_pad = round_up(K, 64)); the per-operator GEMM entry points take K in whole k-tiles;
  *   - LayerNorm: up to 2048 channels, PTF input masks (in_scale / min in_scale) in {1, 2, 4, 8};
  *   - LayerNorm output scale: p2v_ln.inv_out is MULTIPLIED by where the reference divides by the scale - identical for the power-of-two
  *     scales of this path; for any other scale pass p2v_ln.out_scale too and the kernel divides (exact, ABI 3);
@@ -40,6 +44,8 @@ extern "C" {
 
 #define P2V_ABI_VERSION 5
 #define P2V_MAX_TOKENS 608   /* tokens per image of the ViT attention kernel (19 pairs of 32 keys) */
+/* tokens per image the attention kernel covers at this head dimension (0: head_dim not instantiated) */
+int p2v_max_tokens(int head_dim);
 
 enum {
   P2V_OK = 0,
@@ -124,11 +130,14 @@ typedef struct p2v_attn {
 } p2v_attn;
 
 /* nn.GELU -> QAct(PoT) (layers_quant.py:331-333) as an exact threshold table built by p2v_gelu_table_build:
- *   cell i = clamp(floor(fma(y, k, off)), 0, cells-1) of the fp32 pre-activation y;  entry = { float thr; uint32 lo | hi << 8 };
- *   code = (y >= thr) ? (int8)hi : (int8)lo.   table == NULL selects the arithmetic evaluation (A&S erfc + fp64 fallback). */
+ *   u = y * k (exact: k is a power of two) of the fp32 pre-activation y;  cell i = clamp(floor(u) + off, 0, cells-1);
+ *   entry = { float thr * k; uint32 lo | hi << 8 };  code = (u >= thr * k) ? (int8)hi : (int8)lo.
+ *   (Round 4: the epilogues form u straight from the accumulator, fma(acc, colscale * k, bias * k) = RN(acc * colscale + bias) * k, and never
+ *   y itself; before, the cell was floor(fma(y, k, off)) and the entry held thr.  A table must come from THIS library's builder.)
+ *   table == NULL selects the arithmetic evaluation (A&S erfc + fp64 fallback). */
 typedef struct p2v_gelu_tab {
   const void* table; /* dev [cells] 8-byte entries, or NULL */
-  float k, off;      /* k = 2 / s_out (a power of two: y*k is exact), off = -floor(y_lo * k)            */
+  float k, off;      /* k = 2 / s_out (a power of two: y*k is exact), off = -floor(y_lo * k), an integer      */
   int32_t cells;
 } p2v_gelu_tab;
 

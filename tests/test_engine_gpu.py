@@ -527,7 +527,11 @@ def test_ln_gemm_fused_vs_separate_and_oracle(dva, oracle, C_, N, M, kind, table
                                           (1, 193, 2, 64, 5), (1, 224, 2, 64, 4), (1, 209, 1, 32, 4), (1, 64, 2, 64, 4), (1, 1, 1, 32, 4),
                                           # any token count up to 608 (round 3): 65 / 128 / 145 / 257 / 320 / 577 (384^2 / 16) / 608 tokens
                                           (2, 65, 3, 32, 4), (2, 128, 2, 64, 4), (1, 145, 2, 64, 5), (1, 257, 2, 64, 4), (1, 320, 1, 32, 4),
-                                          (1, 577, 2, 64, 5), (1, 577, 1, 32, 4), (1, 608, 1, 64, 4)])
+                                          (1, 577, 2, 64, 5), (1, 577, 1, 32, 4), (1, 608, 1, 64, 4),
+                                          # head dimensions beyond 32 / 64 (round 4): 48, 80 (ViT-H), 96, 128 - two 64-deep MFMA steps per score from 80 on;
+                                          # 544 tokens at 96 and 384 at 128 fill the LDS
+                                          (2, 197, 2, 128, 4), (1, 384, 1, 128, 5), (1, 33, 2, 128, 4), (2, 197, 3, 96, 4), (1, 544, 1, 96, 5),
+                                          (2, 197, 2, 80, 4), (1, 577, 1, 80, 5), (2, 50, 2, 48, 4), (1, 608, 1, 48, 4)])
 def test_lis_attention(dva, oracle, B, N, H, hd, e_at):
     E, S = dva.engine, dva.synth
     D = H * hd
@@ -581,7 +585,7 @@ def test_gelu_threshold_table_exhaustive(dva, oracle, e):
     assert int(bad.item()) == 0
     # the table entries, read back: codes are the oracle's at the thresholds and just below them
     tab = E._GELU_TABLES[(torch.cuda.current_device(), inv_s)][1].cpu().numpy().view(np.uint32).reshape(-1, 2)
-    thr = tab[:, 0].view(np.float32)
+    thr = tab[:, 0].view(np.float32) / np.float32(2.0 * inv_s)          # entries hold thr * k, k = 2 / s (exact: a power of two)
     has = np.isfinite(thr)
     assert 100 < int(has.sum()) < 260
     at = torch.from_numpy(thr[has].copy())
@@ -821,14 +825,19 @@ def test_other_configs_engine_vs_oracle(dva, oracle, name, bits):
         assert flops == orc.flops()
 
 
-@pytest.mark.parametrize('img,patch,dim,depth,heads', [(384, 16, 128, 2, 2), (96, 8, 64, 2, 2), (160, 16, 128, 2, 4)])
+@pytest.mark.parametrize('img,patch,dim,depth,heads', [(384, 16, 128, 2, 2), (96, 8, 64, 2, 2), (160, 16, 128, 2, 4),
+                                                       # head_dim 128 / 96 / 80 / 48 (round 4; vit_fquant.py:108: any dim // num_heads)
+                                                       (160, 16, 256, 2, 2), (96, 8, 192, 2, 2), (96, 8, 320, 1, 4), (64, 8, 192, 2, 4),
+                                                       # widths that are not multiples of the 64-deep k-tile (round 4): 160 = 2 x 80, 144 = 3 x 48
+                                                       (96, 8, 160, 2, 2), (64, 8, 144, 2, 3)])
 def test_other_token_counts_engine_vs_oracle(dva, oracle, img, patch, dim, depth, heads):
     """VisionTransformer takes any img_size (vit_fquant.py:494,535-540): 384^2 / 16 = 577 tokens (the 384-pixel ViT / DeiT variants), 145 and
-    101 tokens: the whole quantized forward through the drop-in surface equals the oracle on every logit; 609+ tokens are refused when the
-    plan is created."""
-    arch = dict(img_size=img, patch_size=patch, embed_dim=dim, depth=depth, num_heads=heads, num_classes=40, mlp_ratio=4.0)
+    101 tokens, and head dimensions 32 ... 128: the whole quantized forward through the drop-in surface equals the oracle on every logit;
+    609+ tokens are refused when the plan is created."""
+    ratio = 3.5 if dim == 160 else 4.0                       # 160 x 3.5 = 560: an MLP width that is not a multiple of 64 either
+    arch = dict(img_size=img, patch_size=patch, embed_dim=dim, depth=depth, num_heads=heads, num_classes=40, mlp_ratio=ratio)
     sd = dva.synth.vit_state_dict(arch, 33)
-    m = dva.VisionTransformer(img_size=img, patch_size=patch, embed_dim=dim, depth=depth, num_heads=heads, num_classes=40, mlp_ratio=4.0, qkv_bias=True,
+    m = dva.VisionTransformer(img_size=img, patch_size=patch, embed_dim=dim, depth=depth, num_heads=heads, num_classes=40, mlp_ratio=ratio, qkv_bias=True,
                               norm_layer=partial(dva.QIntLayerNorm, eps=1e-6), input_quant=True, cfg=dva.Config())
     m.load_state_dict(sd, strict=False)
     m = m.cuda().eval()

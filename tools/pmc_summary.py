@@ -11,7 +11,7 @@ for f in glob.glob(os.path.join(root, '*', '*', '*counter_collection.csv')):
     for r in rows:
         k = r['Kernel_Name'].split('(')[0].replace('void ', '')
         acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
-        if k.startswith('k_gemm_dma<2,'):
+        if k.startswith('k_gemm_dma<2,') or k.startswith('k_gemm_dma<6,'):
             i = seen[k][r['Counter_Name']]
             seen[k][r['Counter_Name']] += 1
             acc[k + (' #even' if i % 2 == 0 else ' #odd')][r['Counter_Name']].append(float(r['Counter_Value']))
