@@ -509,7 +509,7 @@ struct Prof {
   }
   ~Prof() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
 };
-static int prof_pool_size(const p2v_plan* p) { return p ? 7 * p->d.depth + 8 : 0; }
+static int prof_pool_size(const p2v_plan* p) { return p ? 7 * p->d.depth + 10 : 0; }
 
 static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_t* bit_config, int n_cfg, float* logits, void* workspace,
                         size_t workspace_bytes, int stop_after, void* stream, Prof* prof, float* const* qkv_tap = nullptr,
@@ -625,7 +625,12 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
   STEP(P2V_K_GEMM_HEAD, run_gemm(P2V_EPI_HEAD, bufCLS, D, batch, Dk, d.num_classes, p->lin[bit_index(bit_config[n_cfg - 1])][n_cfg - 1], eh, logits,
                 d.num_classes, nullptr, st));
 #undef STEP
-  if (prof) hipEventRecord(prof->ev[prof->used++], st);
+  if (prof) {
+    if (prof->used + 2 > (int)prof->ev.size()) return fail(P2V_E_LAUNCH, "profile: event pool exhausted");
+    hipEventRecord(prof->ev[prof->used++], st);
+    hipEventRecord(prof->ev[prof->used++], st);      // an empty interval: the cost of the event pair itself (P2V_K_EVENT_GAP)
+    prof->kind.push_back(P2V_K_EVENT_GAP);
+  }
   return P2V_OK;
 }
 

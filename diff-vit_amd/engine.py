@@ -15,7 +15,7 @@ EPI_REQUANT, EPI_GELU, EPI_RESID, EPI_EMBED, EPI_HEAD = 0, 1, 2, 3, 4
 E_ARG, E_BITS, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_LAUNCH, E_STATE = -1, -2, -3, -4, -5, -6, -7
 
 KERNEL_KINDS = ('patchify', 'gemm_embed', 'fill_cls', 'layernorm', 'gemm_qkv', 'attention', 'gemm_proj', 'gemm_fc1',
-                'gemm_fc2', 'gemm_head', 'ln_gemm_qkv', 'ln_gemm_fc1')
+                'gemm_fc2', 'gemm_head', 'ln_gemm_qkv', 'ln_gemm_fc1', 'event_gap')
 
 _f, _i, _p, _ll = C.c_float, C.c_int32, C.c_void_p, C.c_longlong
 

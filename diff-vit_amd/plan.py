@@ -353,13 +353,14 @@ class FrozenPlan:
         return out
 
     def profile(self, images, bit_config):
-        """per-launch times (ms, HIP events on the launch stream) of one forward: [(kind_name, ms), ...]."""
+        """per-launch times (ms, HIP events on the launch stream) of one forward: [(kind_name, ms), ...]; the last entry, 'event_gap', is an
+        interval with no launch in it - what the event pair adds to every interval."""
         images, cfg = self._check(images, bit_config)
         B = images.shape[0]
         with torch.cuda.device(self.device):
             ws = self.workspace(B)
             out = torch.empty(B, self.arch['num_classes'], dtype=torch.float32, device=self.device)
-            n_max = 7 * self.depth + 8
+            n_max = 7 * self.depth + 10
             ms = (C.c_float * n_max)()
             kind = (C.c_int32 * n_max)()
             n = E.lib().p2v_forward_profile(self._handle, E.ptr(images), B, cfg, len(bit_config), E.ptr(out), E.ptr(ws), ws.numel(),
@@ -381,7 +382,7 @@ class FrozenPlan:
             return [per], sum(ms for _, ms in per)
         out = torch.empty(B, self.arch['num_classes'], dtype=torch.float32, device=self.device)
         L = E.lib()
-        n_max = 7 * self.depth + 8
+        n_max = 7 * self.depth + 10
         with torch.cuda.device(self.device):
             self.forward_streams(images, bit_config, out, n_streams, sizes)          # streams and workspaces exist
             torch.cuda.synchronize(self.device)

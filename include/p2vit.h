@@ -249,7 +249,9 @@ int p2v_forward_taps(p2v_plan* plan, const float* images, int batch, const int8_
 enum {
   P2V_K_PATCHIFY = 0, P2V_K_GEMM_EMBED = 1, P2V_K_FILL_CLS = 2, P2V_K_LAYERNORM = 3, P2V_K_GEMM_QKV = 4,
   P2V_K_ATTENTION = 5, P2V_K_GEMM_PROJ = 6, P2V_K_GEMM_FC1 = 7, P2V_K_GEMM_FC2 = 8, P2V_K_GEMM_HEAD = 9,
-  P2V_K_LN_GEMM_QKV = 10, P2V_K_LN_GEMM_FC1 = 11   /* LayerNorm fused into the GEMM that consumes it (p2v_ln_gemm_i8) */
+  P2V_K_LN_GEMM_QKV = 10, P2V_K_LN_GEMM_FC1 = 11,  /* LayerNorm fused into the GEMM that consumes it (p2v_ln_gemm_i8) */
+  P2V_K_EVENT_GAP = 12     /* not a launch: the last interval of a profile pass, two events with NOTHING between them - what an event pair
+                              itself adds to every interval on this stream (subtract it to compare with rocprofv3's kernel durations) */
 };
 
 /* Same as p2v_forward, with a hipEvent recorded on `stream` between consecutive launches; synchronises on the

@@ -117,7 +117,7 @@ def ln_gemm_case(i):
 
 def attn_case(i):
     global fails
-    hd = 64 if i % 2 else 32
+    hd = [32, 64, 48, 80, 96, 128][i % 6]             # every instantiated head dimension (two 64-deep MFMA steps per score from 80 on)
     H = int(torch.randint(1, 5, (1,), generator=g))
     N = [197, 50, 17, 33, 64][i % 5]
     B = int(torch.randint(1, 4, (1,), generator=g))
