@@ -29,7 +29,7 @@ __device__ __forceinline__ unsigned lis_prob_pair(float r0, float r1) {
   const unsigned hi2 = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
   const unsigned eb = __builtin_bit_cast(unsigned, __builtin_bit_cast(v2u16, hi2) + (v2u16){0x40, 0x40}) & 0x7F807F80u;      // E << 7, twice
   unsigned out;
-  asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(out) : "v"(0x47804780u), "v"(eb));                                          // sat((143 - E) << 7)
+  asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(out) : "s"(0x47804780u), "v"(eb));                                          // sat((143 - E) << 7)
   return out;
 }
 

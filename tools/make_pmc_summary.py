@@ -24,7 +24,7 @@ def tr(prefixes, fetch_mul):
 
 
 def resid(which):     # proj = even dispatches, fc2 = odd (tools/pmc_summary.py), whichever tile height the launcher picked
-    ks = [k for k in d if k.startswith('k_gemm_dma<2,') and k.endswith(which) and 'FETCH_SIZE' in d[k] and 'WRITE_SIZE' in d[k]]
+    ks = [k for k in d if (k.startswith('k_gemm_dma<6,') or k.startswith('k_gemm_dma<2,')) and k.endswith(which) and 'FETCH_SIZE' in d[k] and 'WRITE_SIZE' in d[k]]
     if not ks:
         return None
     v = d[max(ks, key=lambda k: d[k]['dispatches'])]
