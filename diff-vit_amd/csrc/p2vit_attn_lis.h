@@ -88,8 +88,8 @@ __global__ __launch_bounds__(512, HD > 64 ? 2 : (NKP <= 7 ? 4 : (NKP <= 10 ? 3 :
     long long e = z << (32 - q);
     e = e < 0 ? 0 : e;
     const float ef = (float)e;                   // exact: z < 2^24; 1 <= e <= 2^56 (z > 0 on (x0, 0], shift >= 0)
-    reinterpret_cast<long long*>(lutE)[tid] = e;
     // the fp64 reciprocal (IEEE division, correctly rounded): the per-score quotient is one fp64 multiply by it, see below
+    reinterpret_cast<long long*>(lutE)[tid] = e;
     reinterpret_cast<double*>(lutFR)[tid] = 1.0 / (double)ef;
     if (tid == 0) {
       reinterpret_cast<long long*>(lutE)[256] = 0;

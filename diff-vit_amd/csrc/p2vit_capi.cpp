@@ -83,10 +83,10 @@ struct p2v_plan {
   p2v_ln final_ln;
   float head_inv_s, head_s;
   bool head_set;
-  // LayerNorm constants folded at plan creation (LnPre): [block][6] in the order ln1[0], ln1[1], ln2[0][0], ln2[0][1], ln2[1][0], ln2[1][1];
-  // the arrays live in one device buffer per block, owned by the plan
-  std::vector<LnPre> ln_pre;
+  // LayerNorm constants folded at plan creation (p2v_ln.pre of the plan's copies of ln1 / ln2 / the final norm): the arrays live in one device
+  // buffer per block (+ one for the final norm), owned by the plan
   std::vector<float*> ln_pre_buf;
+  float* final_pre_buf = nullptr;
   std::vector<char> block_folded;
   // tables of the pre-folded RESID epilogue (p2v_resid_prefold): [block][proj = 0 / fc2 = 1][bit index]; null = the generic epilogue.  One device
   // buffer per block, owned by the plan
@@ -100,6 +100,7 @@ struct p2v_plan {
       if (b) (void)hipFree(b);
     for (float* b : resid_buf)
       if (b) (void)hipFree(b);
+    if (final_pre_buf) (void)hipFree(final_pre_buf);
     if (sw) (void)hipSetDevice(prev);
   }
 };
@@ -116,6 +117,7 @@ extern int g_ln_gemm;
 extern int g_ln_gemm_ver;
 extern int g_gemm_tile;
 extern int g_resid_pre;
+extern int g_ln_pre;
 // Tuning / A-B switches read once per process (first plan or first version query).  None of them changes results:
 // P2V_LN_GENERIC forces the generic LayerNorm chain (bit-identical to the fast one, both are tested).
 static void read_env_once() {
@@ -130,6 +132,8 @@ static void read_env_once() {
   if (e && atoi(e) >= 1 && atoi(e) <= 3) g_ln_gemm_ver = atoi(e);
   e = getenv("P2V_GEMM_TILE");
   if (e && (atoi(e) == 0 || atoi(e) == 128 || atoi(e) == 256)) g_gemm_tile = atoi(e);
+  e = getenv("P2V_LN_PRE");
+  if (e) g_ln_pre = atoi(e) != 0;
   e = getenv("P2V_RESID_PRE");
   if (e) g_resid_pre = atoi(e) != 0;
   e = getenv("P2V_LN_ROWS");
@@ -155,6 +159,7 @@ int p2v_set_tuning(const char* name, int value) {
   if (!strcmp(name, "ln_rows") && value >= 1 && value <= 64) { g_ln_rows = value; return P2V_OK; }
   if (!strcmp(name, "attn_waves") && value >= 4 && value <= 8) { g_attn_waves = value; return P2V_OK; }
   if (!strcmp(name, "resid_pre")) { g_resid_pre = value != 0; return P2V_OK; }
+  if (!strcmp(name, "ln_pre")) { g_ln_pre = value != 0; return P2V_OK; }
   if (!strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) { g_gemm_tile = value; return P2V_OK; }
   return fail(P2V_E_ARG, "p2v_set_tuning: unknown switch or value out of range: %s = %d", name, value);
 }
@@ -196,7 +201,6 @@ int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
   }
   p->blocks.resize(d.depth);
   p->block_set.assign(d.depth, 0);
-  p->ln_pre.assign((size_t)d.depth * 6, LnPre{nullptr, nullptr, 0.f, 0.f, 0.f, 0, 0});
   p->ln_pre_buf.assign(d.depth, nullptr);
   p->block_folded.assign(d.depth, 0);
   p->resid_tab.assign((size_t)d.depth * 4, nullptr);
@@ -301,79 +305,75 @@ static void build_resid_tables(p2v_plan* plan, int block) {
     }
 }
 
-// The fold of ln_prepare (p2vit_ln.hip), once per plan instead of once per workgroup: the same fp32 products and the same tests on the
-// host (this file is compiled without contraction too), the results uploaded next to the caller's arrays - on the device that OWNS the
-// caller's arrays, whatever the process's current device is (a plan built for cuda:1 while cuda:0 is current).  Returns false, with the
-// reason in p2v_last_error(), when the constants could not be folded: the block's kernels then fold per workgroup, with the same results.
+// The fold of ln_prepare (p2vit_ln.hip), once per LayerNorm instead of once per workgroup: the same fp32 products and the same tests on the
+// host (this file is compiled without contraction too); `dev` receives gamma / out_scale and beta / out_scale, each padded with zeros to
+// Cp = round_up(C, 256) channels.  The current device must be the one that owns the arrays.
+static hipError_t fold_one_ln(const p2v_ln& l, int C, float* dev, p2v_ln_pre* out) {
+  const int Cp = round_up(C, 256);                             // (a row group of 64 lanes covers 256 channels per chunk)
+  std::vector<float> g(C), b(C), io(C), pm(C), host((size_t)2 * Cp, 0.f);
+  hipError_t e = hipMemcpy(g.data(), l.gamma, C * sizeof(float), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(b.data(), l.beta, C * sizeof(float), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(io.data(), l.inv_out, C * sizeof(float), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(pm.data(), l.post_mul, C * sizeof(float), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return e;
+  float* go = host.data();
+  float* bo = go + Cp;
+  int pot = 1, pm1 = 1;
+  float gmin = 3.0e38f, gmax = 0.f, bmax = 0.f;
+  for (int c = 0; c < C; ++c) {
+    unsigned ib;
+    memcpy(&ib, &io[c], 4);
+    const int p2 = (int)((ib & 0x807FFFFFu) == 0u) & (int)((ib >> 23) - 32u <= 190u);    // +2^e, far from under/overflow
+    go[c] = g[c] * io[c];
+    bo[c] = b[c] * io[c];
+    const float ga = fabsf(go[c]), ba = fabsf(bo[c]);
+    const int gok = (int)(g[c] == 0.f) | ((int)(ga >= 1.0e-30f) & (int)(ga <= 1.0e30f));
+    const int bok = (int)(b[c] == 0.f) | ((int)(ba >= 1.0e-30f) & (int)(ba <= 1.0e30f));
+    pot &= p2 & gok & bok;
+    pm1 &= (int)(pm[c] == 1.f);
+    gmin = fminf(gmin, ga);
+    gmax = fmaxf(gmax, ga);
+    bmax = fmaxf(bmax, ba);
+  }
+  e = hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) *out = p2v_ln_pre{dev, dev + Cp, gmin, gmax, bmax, pot, pm1};
+  return e;
+}
+static const p2v_ln_pre kNoPre = {nullptr, nullptr, 0.f, 0.f, 0.f, 0, 0};
+
+// The plan's six LayerNorms of a block, folded on the device that OWNS the caller's arrays, whatever the process's current device is (a
+// plan built for cuda:1 while cuda:0 is current).  Returns false, with the reason in p2v_last_error(), when the constants could not be
+// folded: the block's kernels then fold per workgroup, with the same results.
 static bool fold_ln_constants(p2v_plan* plan, int block) {
-  const int C = plan->d.embed_dim, Cp = round_up(C, 256);      // (a row group of 64 lanes covers 256 channels per chunk)
+  const int C = plan->d.embed_dim, Cp = round_up(C, 256);
+  p2v_block& blk = plan->blocks[block];
+  auto ln_at = [&](int i) -> p2v_ln& { return i < 2 ? blk.ln1[i] : blk.ln2[(i - 2) >> 1][(i - 2) & 1]; };
   // stale state first: a second p2v_plan_set_block on this block must never leave the constants of the previous arrays behind
-  for (int i = 0; i < 6; ++i) plan->ln_pre[(size_t)block * 6 + i] = LnPre{nullptr, nullptr, 0.f, 0.f, 0.f, 0, 0};
-  const p2v_block& blk = plan->blocks[block];
-  int prev = -1, own = -1;
-  hipPointerAttribute_t pa;
-  if (hipGetDevice(&prev) != hipSuccess || hipPointerGetAttributes(&pa, blk.ln1[0].gamma) != hipSuccess) {
-    (void)hipGetLastError();
+  for (int i = 0; i < 6; ++i) ln_at(i).pre = kNoPre;
+  OwnerDevice own(blk.ln1[0].gamma);
+  if (!own.ok()) {
     fail(P2V_OK, "p2v_plan_set_block: LayerNorm constants of block %d not folded at plan time (cannot locate the device of gamma)", block);
     return false;
   }
-  own = pa.device;
-  if (plan->device >= 0 && plan->device != own) {
-    fail(P2V_OK, "p2v_plan_set_block: block %d lives on device %d, earlier blocks on device %d: not folded at plan time", block, own, plan->device);
+  if (plan->device >= 0 && plan->device != own.own) {
+    fail(P2V_OK, "p2v_plan_set_block: block %d lives on device %d, earlier blocks on device %d: not folded at plan time", block, own.own, plan->device);
     return false;
   }
-  struct DeviceGuard {          // set the owning device for the sync / malloc / copies below, restore on every path
-    int prev, own;
-    DeviceGuard(int p, int o) : prev(p), own(o) { if (own != prev) (void)hipSetDevice(own); }
-    ~DeviceGuard() { if (own != prev) (void)hipSetDevice(prev); }
-  } guard(prev, own);
   hipError_t e = hipDeviceSynchronize();                        // the caller's uploads may still be in flight on another stream
   float* dev = plan->ln_pre_buf[block];
   if (e == hipSuccess && !dev) e = hipMalloc(&dev, (size_t)12 * Cp * sizeof(float));
+  p2v_ln_pre pre[6];
+  if (e == hipSuccess) {
+    plan->ln_pre_buf[block] = dev;
+    plan->device = own.own;
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = fold_one_ln(ln_at(i), C, dev + (size_t)(2 * i) * Cp, &pre[i]);
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();                                    // do not leave the error for an unrelated CHECK_LAUNCH
     fail(P2V_OK, "p2v_plan_set_block: LayerNorm constants of block %d not folded at plan time (%s)", block, hipGetErrorString(e));
     return false;
   }
-  plan->ln_pre_buf[block] = dev;
-  plan->device = own;
-  std::vector<float> g(C), b(C), io(C), pm(C), host((size_t)12 * Cp, 0.f);
-  LnPre pre[6];
-  for (int i = 0; i < 6 && e == hipSuccess; ++i) {
-    const p2v_ln& l = i < 2 ? blk.ln1[i] : blk.ln2[(i - 2) >> 1][(i - 2) & 1];
-    e = hipMemcpy(g.data(), l.gamma, C * sizeof(float), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(b.data(), l.beta, C * sizeof(float), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(io.data(), l.inv_out, C * sizeof(float), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(pm.data(), l.post_mul, C * sizeof(float), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) break;
-    float* go = host.data() + (size_t)(2 * i) * Cp;
-    float* bo = go + Cp;
-    int pot = 1, pm1 = 1;
-    float gmin = 3.0e38f, gmax = 0.f, bmax = 0.f;
-    for (int c = 0; c < C; ++c) {
-      unsigned ib;
-      memcpy(&ib, &io[c], 4);
-      const int p2 = (int)((ib & 0x807FFFFFu) == 0u) & (int)((ib >> 23) - 32u <= 190u);    // +2^e, far from under/overflow
-      go[c] = g[c] * io[c];
-      bo[c] = b[c] * io[c];
-      const float ga = fabsf(go[c]), ba = fabsf(bo[c]);
-      const int gok = (int)(g[c] == 0.f) | ((int)(ga >= 1.0e-30f) & (int)(ga <= 1.0e30f));
-      const int bok = (int)(b[c] == 0.f) | ((int)(ba >= 1.0e-30f) & (int)(ba <= 1.0e30f));
-      pot &= p2 & gok & bok;
-      pm1 &= (int)(pm[c] == 1.f);
-      gmin = fminf(gmin, ga);
-      gmax = fmaxf(gmax, ga);
-      bmax = fmaxf(bmax, ba);
-    }
-    pre[i] = LnPre{dev + (size_t)(2 * i) * Cp, dev + (size_t)(2 * i + 1) * Cp, gmin, gmax, bmax, pot, pm1};
-  }
-  if (e == hipSuccess) e = hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    fail(P2V_OK, "p2v_plan_set_block: LayerNorm constants of block %d not folded at plan time (%s)", block, hipGetErrorString(e));
-    return false;
-  }
-  for (int i = 0; i < 6; ++i) plan->ln_pre[(size_t)block * 6 + i] = pre[i];
+  for (int i = 0; i < 6; ++i) ln_at(i).pre = pre[i];
   return true;
 }
 
@@ -427,6 +427,20 @@ int p2v_plan_set_head(p2v_plan* plan, const p2v_ln* final_ln, float inv_s_out, f
     return fail(P2V_E_ARG, "p2v_plan_set_head: LayerNorm constants missing");
   if (!(inv_s_out > 0.f) || !(s_out > 0.f)) return fail(P2V_E_ARG, "p2v_plan_set_head: act_out scale must be positive");
   plan->final_ln = *final_ln;
+  plan->final_ln.pre = kNoPre;
+  {   // the final norm's constants, folded like a block's (best effort: the per-workgroup fold gives the same codes)
+    OwnerDevice own(final_ln->gamma);
+    const int C = plan->d.embed_dim;
+    if (own.ok() && (plan->device < 0 || plan->device == own.own) && hipDeviceSynchronize() == hipSuccess) {
+      if (!plan->final_pre_buf && hipMalloc(&plan->final_pre_buf, (size_t)2 * round_up(C, 256) * sizeof(float)) != hipSuccess) plan->final_pre_buf = nullptr;
+      p2v_ln_pre pre;
+      if (plan->final_pre_buf && fold_one_ln(*final_ln, C, plan->final_pre_buf, &pre) == hipSuccess) {
+        plan->final_ln.pre = pre;
+        plan->device = own.own;
+      }
+    }
+    (void)hipGetLastError();
+  }
   plan->head_inv_s = inv_s_out;
   plan->head_s = s_out;
   plan->head_set = true;
@@ -575,7 +589,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     const int bq = bit_index(bc[0]), bp = bit_index(bc[1]), b1 = bit_index(bc[2]), b2 = bit_index(bc[3]);
     // norm1 -> /channel_scale -> qact0                                     vit_fquant.py:431-434,284-289
     LnArgs ln{bufX, D, M, D, b.ln1[bq], bufLN, D};
-    ln.pre = p->ln_pre[(size_t)i * 6 + bq];
+    ln.pre = b.ln1[bq].pre;
     // qkv -> qact1                                                          vit_fquant.py:293,307
     p2v_epilogue e{};
     e.inv_s_out = b.inv_s_qkv[bq];
@@ -597,7 +611,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
     STEP(P2V_K_GEMM_PROJ, run_gemm(P2V_EPI_RESID, bufATT, D, M, Dk, D, p->lin[bp][2 + 4 * i], ep, bufX, D, nullptr, st));
     // norm2 (attention's channel scale!) -> /mlp.channel_scale -> mlp.qact0 vit_fquant.py:464, layers_quant.py:305-311
     LnArgs ln2{bufX, D, M, D, b.ln2[bq][b1], bufLN, D};
-    ln2.pre = p->ln_pre[(size_t)i * 6 + 2 + 2 * bq + b1];
+    ln2.pre = b.ln2[bq][b1].pre;
     // fc1 -> GELU -> qact1                                                  layers_quant.py:316,331-333
     p2v_epilogue e1{};
     e1.inv_s_out = b.inv_s_fc1;
@@ -618,6 +632,7 @@ static int forward_impl(p2v_plan* p, const float* images, int batch, const int8_
   }
   // norm over the cls rows only ([:,0]) -> qact2 -> head -> act_out         vit_fquant.py:766-796
   LnArgs lf{bufX, (long long)T * D, batch, D, p->final_ln, bufCLS, D};
+  lf.pre = p->final_ln.pre;
   STEP(P2V_K_LAYERNORM, launch_rc(p2v_launch_layernorm(lf, st), "int_layernorm"));
   p2v_epilogue eh{};
   eh.inv_s_out = p->head_inv_s;
@@ -717,6 +732,27 @@ int p2v_gemm_i8(int kind, const int8_t* A, int lda, int M, int K, int N, const p
   return run_gemm(kind, A, lda, M, K, N, *lin, *epi, out, ldo, out_codes, (hipStream_t)stream);
 }
 
+size_t p2v_ln_prefold_bytes(int C) { return C > 0 ? (size_t)2 * round_up(C, 256) * sizeof(float) : 0; }
+
+int p2v_ln_prefold(p2v_ln* ln, int C, float* buf, size_t buf_bytes) {
+  if (!ln || !buf) return fail(P2V_E_ARG, "p2v_ln_prefold: null argument");
+  ln->pre = kNoPre;
+  if (C <= 0 || C % 4 || C > 2048) return fail(P2V_E_SHAPE, "p2v_ln_prefold: C must be a positive multiple of 4 up to 2048");
+  if (!ln->gamma || !ln->beta || !ln->inv_out || !ln->post_mul) return fail(P2V_E_ARG, "p2v_ln_prefold: LayerNorm constants missing");
+  if (buf_bytes < p2v_ln_prefold_bytes(C)) return fail(P2V_E_WORKSPACE, "p2v_ln_prefold: buffer %zu < %zu bytes", buf_bytes, p2v_ln_prefold_bytes(C));
+  OwnerDevice own(buf);
+  if (!own.ok()) return fail(P2V_E_ARG, "p2v_ln_prefold: buf is not a device pointer");
+  hipError_t e = hipDeviceSynchronize();                        // the caller's uploads may still be in flight
+  p2v_ln_pre pre;
+  if (e == hipSuccess) e = fold_one_ln(*ln, C, buf, &pre);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(P2V_E_LAUNCH, "p2v_ln_prefold: %s", hipGetErrorString(e));
+  }
+  ln->pre = pre;
+  return P2V_OK;
+}
+
 size_t p2v_resid_prefold_bytes(int N) { return N > 0 ? resid_tab_floats(N) * sizeof(float) : 0; }
 
 int p2v_resid_prefold(const p2v_linear* lin, const p2v_epilogue* epi, int N, float* tab, size_t tab_bytes, int* usable, void* stream) {
@@ -736,6 +772,7 @@ int p2v_int_layernorm(const int8_t* x, long long row_stride, int rows, int C, co
   if (C % 4 || row_stride % 4 || out_stride % 4) return fail(P2V_E_UNSUPPORTED, "C and strides must be multiples of 4");
   if (rows <= 0) return fail(P2V_E_SHAPE, "rows must be positive");
   LnArgs a{x, row_stride, rows, C, *ln, out, out_stride};
+  a.pre = ln->pre;                       // optional: constants folded ahead of the launch (p2v_ln_prefold)
   return launch_rc(p2v_launch_layernorm(a, (hipStream_t)stream), "int_layernorm");
 }
 
@@ -749,6 +786,7 @@ int p2v_ln_gemm_i8(int kind, const int8_t* x, long long row_stride, int M, int C
   if (kind == P2V_EPI_GELU && check_gelu_tab("p2v_ln_gemm_i8", epi->gelu) != P2V_OK) return P2V_E_ARG;
   read_env_once();
   LnArgs a{x, row_stride, M, C, *ln, ln_out, C};
+  a.pre = ln->pre;
   return run_ln_gemm(kind, a, *lin, *epi, N, out, (hipStream_t)stream);
 }
 

@@ -25,15 +25,9 @@ struct GemmArgs {
 #endif
 };
 
-// LayerNorm constants folded once, when a plan is created (p2v_plan_set_block), instead of by every workgroup (ln_prepare): gamma / out_scale
-// and beta / out_scale padded with zeros to a multiple of 256 channels, their extreme magnitudes and the two tests of the fast chain.
-// gm == nullptr: the kernel folds them itself (per-operator entry points, Swin op lists).
-struct LnPre {
-  const float* gm;
-  const float* bt;
-  float gmin, gmax, bmax;
-  int pot, pm_one;
-};
+// LayerNorm constants folded ahead of the launches (p2v_ln.pre, include/p2vit.h) instead of by every workgroup (ln_prepare).
+// gm == nullptr: the kernel folds them itself.
+typedef p2v_ln_pre LnPre;
 
 struct LnArgs {
   const int8_t* x;

@@ -968,6 +968,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_ln_gemm2(LnArgs a, GemmArgs g) 
 #ifdef P2V_DIAG
 extern unsigned long long* g_gemm_stamps;
 #endif
+int g_ln_pre = 1;         // P2V_LN_PRE=0: ignore p2v_ln.pre, every workgroup folds the constants itself (A/B and parity runs; same codes)
 int g_ln_generic = 0;     // P2V_LN_GENERIC=1
 // LayerNorm + GEMM in one launch.  Returns -3 when the shape is outside what the fused kernel is instantiated for (callers then
 // run p2v_launch_layernorm + p2v_launch_gemm).
@@ -1011,6 +1012,7 @@ int p2v_launch_ln_gemm(int epi, const LnArgs& a_, const GemmArgs& g0, hipStream_
   if (a_.row_stride < 0 || a_.row_stride > (1 << 24)) return -3;       // the kernels address a workgroup's 64 rows with 32-bit offsets
   LnArgs a = a_;
   a.force_generic = g_ln_generic;
+  if (!g_ln_pre) a.pre.gm = nullptr;
   GemmArgs g = g0;
   g.tiles_n = (g.N + GBN - 1) / GBN;
 #ifdef P2V_DIAG
@@ -1045,6 +1047,7 @@ int g_ln_rows = 4;        // P2V_LN_ROWS: consecutive rows per half wave
 int p2v_launch_layernorm(const LnArgs& a_, hipStream_t st) {
   LnArgs a = a_;
   a.force_generic = g_ln_generic;
+  if (!g_ln_pre) a.pre.gm = nullptr;
   a.rows_per_half = g_ln_rows;
   const int LN_ROWS = g_ln_rows;
   // one row per WAVE above 384 channels (64 lanes x 4 channels x up to 8 groups = 2048 channels): the per-lane constants of a half-wave

@@ -29,8 +29,13 @@ class Linear(C.Structure):
     _fields_ = [('w_codes', _p), ('colscale', _p), ('bias', _p), ('w_frag', _p), ('packed4', _i)]
 
 
+class LnPre(C.Structure):
+    """``p2v_ln_pre``: LayerNorm constants folded ahead of the launches (filled by ``p2v_ln_prefold``)."""
+    _fields_ = [('gm', _p), ('bt', _p), ('gmin', _f), ('gmax', _f), ('bmax', _f), ('pot', _i), ('pm_one', _i)]
+
+
 class Ln(C.Structure):
-    _fields_ = [('s1', _f), ('mask', _p), ('gamma', _p), ('beta', _p), ('inv_out', _p), ('post_mul', _p), ('out_scale', _p)]
+    _fields_ = [('s1', _f), ('mask', _p), ('gamma', _p), ('beta', _p), ('inv_out', _p), ('post_mul', _p), ('out_scale', _p), ('pre', LnPre)]
 
 
 class Attn(C.Structure):
@@ -100,6 +105,9 @@ def lib():
     L.p2v_plan_set_head.argtypes = [_p, C.POINTER(Ln), _f, _f]
     L.p2v_plan_block_prefolded.argtypes = [_p, _i]
     L.p2v_plan_resid_prefolded.argtypes = [_p, _i]
+    L.p2v_ln_prefold_bytes.argtypes = [_i]
+    L.p2v_ln_prefold_bytes.restype = C.c_size_t
+    L.p2v_ln_prefold.argtypes = [C.POINTER(Ln), _i, _p, C.c_size_t]
     L.p2v_max_tokens.argtypes = [_i]
     L.p2v_resid_prefold_bytes.argtypes = [_i]
     L.p2v_resid_prefold_bytes.restype = C.c_size_t

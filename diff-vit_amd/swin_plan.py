@@ -103,7 +103,15 @@ class SwinPlan:
             raise NotImplementedError('LayerNorm input scale ratios up to %g over %d channels exceed the exact 32-bit statistics' % (mask_max, C_))
         t = [self._dev(torch.round(s_in_vec / s1)), self._dev(self.W[prefix + '.weight']), self._dev(self.W[prefix + '.bias']),
              self._dev(torch.full((C_,), 1.0 / float(s_out))), self._dev(torch.ones(C_))]
-        return E.Ln(float(s1), *[E.ptr(x) for x in t])
+        ln = E.Ln(float(s1), *[E.ptr(x) for x in t])
+        # the constants folded once here instead of by every workgroup of every launch (p2v_ln_prefold: gamma / out_scale, beta / out_scale and
+        # the fast-chain tests; the wide stages' stand-alone LayerNorm folds for only 16 - 32 rows per workgroup otherwise)
+        L = E.lib()
+        nbytes = L.p2v_ln_prefold_bytes(C_)
+        buf = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+        self._keep.append(buf)
+        E.check(L.p2v_ln_prefold(C.byref(ln), C_, E.ptr(buf), nbytes))
+        return ln
 
     # ---- plan ----------------------------------------------------------------------------------------------------------
     def _build(self):

@@ -109,6 +109,17 @@ typedef struct p2v_linear {
  *              (IEEE) exactly where the reference does (layers.py:279-286); with NULL it multiplies by inv_out, which for such a
  *              scale lands the 8-bit multiplier M one step away on about 1e-5 of the elements
  * post_mul[c] = out_scale[c] / next_channel_scale[c] / next_act_scale  (power of two). */
+/* Constants of a LayerNorm folded ahead of its launches (round 4, ABI 5; optional: gm == NULL and every kernel folds per workgroup, with the
+ * same codes): gamma * inv_out and beta * inv_out, each padded with zeros to round_up(C, 256) channels, their extreme magnitudes and the two
+ * tests of the fast chain (1 / out_scale a power of two everywhere; post_mul == 1 everywhere).  Filled by p2v_ln_prefold; the frozen plan of
+ * p2v_forward folds its own copies and ignores what the caller passes here. */
+typedef struct p2v_ln_pre {
+  const float* gm;        /* dev [round_up(C, 256)] */
+  const float* bt;        /* dev [round_up(C, 256)] */
+  float gmin, gmax, bmax;
+  int32_t pot, pm_one;
+} p2v_ln_pre;
+
 typedef struct p2v_ln {
   float s1;
   const float* mask;      /* dev [C] */
@@ -117,7 +128,12 @@ typedef struct p2v_ln {
   const float* inv_out;   /* dev [C] */
   const float* post_mul;  /* dev [C] */
   const float* out_scale; /* dev [C] or NULL (ABI 3) */
+  p2v_ln_pre pre;         /* optional (ABI 5), see above */
 } p2v_ln;
+/* Fold the constants of *ln for C channels into buf (dev, p2v_ln_prefold_bytes(C) bytes, owned by the caller, must outlive the launches) and
+ * set ln->pre.  Reads the arrays back to the host: synchronises the device; call it after the arrays have been written. */
+size_t p2v_ln_prefold_bytes(int C);
+int p2v_ln_prefold(p2v_ln* ln, int C, float* buf, size_t buf_bytes);
 
 /* (q @ k^T) * scale -> qact_attn1 -> QIntSoftmax (log-int-softmax, uint4) -> @ v -> qact2
  * (vit_fquant.py:309-326, layers.py:323-376). */
