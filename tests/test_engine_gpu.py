@@ -436,6 +436,23 @@ def test_int_layernorm(dva, oracle, C_, rows):
     got = out.cpu().float()
     assert torch.equal(got, ref), int((got != ref).sum())
     assert ln.abs().max() > 127
+    # the same launch on constants folded ahead of it (p2v_ln_prefold -> p2v_ln.pre, round 4): identical codes; the switch ignores them
+    L = E.lib()
+    nb = L.p2v_ln_prefold_bytes(C_)
+    buf = torch.empty(nb // 4, dtype=torch.float32, device='cuda')
+    E.check(L.p2v_ln_prefold(C.byref(lnp), C_, E.ptr(buf), nb))
+    assert lnp.pre.gm and lnp.pre.pot == 1 and lnp.pre.pm_one == 0 and lnp.pre.gmax >= lnp.pre.gmin > 0
+    out2 = torch.zeros(rows, C_, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_int_layernorm(E.ptr(dev[0]), C_, rows, C_, C.byref(lnp), E.ptr(out2), C_, E.stream_ptr()))
+    assert torch.equal(out2, out)
+    assert L.p2v_set_tuning(b'ln_pre', 0) == 0
+    try:
+        out3 = torch.zeros(rows, C_, dtype=torch.int8, device='cuda')
+        E.check(L.p2v_int_layernorm(E.ptr(dev[0]), C_, rows, C_, C.byref(lnp), E.ptr(out3), C_, E.stream_ptr()))
+    finally:
+        L.p2v_set_tuning(b'ln_pre', 1)
+    assert torch.equal(out3, out)
+    assert L.p2v_ln_prefold(C.byref(lnp), C_, E.ptr(buf), 16) == E.E_WORKSPACE and not lnp.pre.gm
 
 
 @pytest.mark.parametrize('C_,N,M,kind,table,pot', [(384, 1152, 333, 'requant', False, True), (384, 1536, 777, 'gelu', True, True),
