@@ -172,7 +172,7 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH, help='images per GPU (BASELINE config 2: 256)')
     ap.add_argument('--bits', type=int, default=8, choices=(4, 8))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--streams', type=int, default=3, help='HIP streams the per-GPU batch is sliced over (3: one slice of 85-86 images is about one fused LayerNorm+GEMM workgroup per CU)')
+    ap.add_argument('--streams', type=int, default=3, help='side HIP streams the per-GPU batch is sliced over; one more, smaller slice runs on the caller\'s stream (3: 68 + 68 + 68 + 52 of 256 images - four kernels in flight, FrozenPlan.slice_sizes)')
     ap.add_argument('--model', default=MODEL, choices=('deit_tiny', 'deit_small', 'deit_base', 'vit_base', 'swin_tiny', 'swin_base'))
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for a rehearsal on one GPU)')
     ap.add_argument('--slices', default=None, help='explicit batch slices, e.g. 83,83,83,7 (default: FrozenPlan.slice_sizes)')
@@ -269,7 +269,8 @@ def main():
     bits = [args.bits] * (4 * arch['depth'] + 2)
     logits = torch.empty(B, arch['num_classes'], device=dev)
     # == model(x, bits)[0]; the per-GPU batch runs as contiguous slices on their own HIP streams (images are independent; the kernels
-    # of one slice fill the latency/VALU gaps of the others; 3 slices measured best: 92.3 vs 90.3 k img/s at 2, 67.7 k at 4).  The N-GPU step is the product's data-parallel runner: every rank forwards
+    # of one slice fill the latency/VALU gaps of the others; three side streams + the caller's stream = four kernels in flight measured best:
+    # round 4, +1.7 % over three slices; a fourth SIDE stream collapses to 57 k img/s).  The N-GPU step is the product's data-parallel runner: every rank forwards
     # its own shard, then ONE all-gather of the logits -- dp.DataParallelForward, the class the gloo tests exercise.
     slices = [int(v) for v in args.slices.split(',')] if args.slices else plan.slice_sizes(B, args.streams)
     runner = dva.dp.DataParallelForward(lambda xs: plan.forward_streams(xs, bits, logits, args.streams, slices), arch['num_classes'],

@@ -304,13 +304,21 @@ class FrozenPlan:
         return out
 
     def slice_sizes(self, batch, n_streams=3):
-        """Batch slices of ``forward_streams``: a balanced contiguous split (256 -> 86 + 85 + 85).  Measured in round 3
-        (profiles/r03_slicing.txt): slices cut to one fused-kernel workgroup per CU (83 + 83 + 83 + 7), two slices of 128 or uneven
-        splits all give the same step time within 1 % -- the step runs at the board's power limit, not at a scheduling limit."""
+        """Batch slices of ``forward_streams``: ``n_streams`` slices for the side streams plus ONE more, smaller, for the caller's own stream
+        (256 -> 68 + 68 + 68 + 52).  Four kernels in flight on four hardware queues is what the runtime sustains - a fourth SIDE stream (five
+        streams with the caller's) collapses to 57 k img/s - and the fourth slice is worth +1.7 % over three (86 + 85 + 85) in the same call, with
+        or without an initialised RCCL group (round 4, profiles/r04_slices.txt; 64 x 4, 60 + 60 + 60 + 76 and 70 + 62 + 62 + 62 lie within
+        0.5 % of each other).  Round 3 (profiles/r03_slicing.txt): any split into THREE gives the same step time within 1 %."""
         if n_streams <= 1 or batch < 2 * n_streams:
             return [batch]
-        q, r = divmod(batch, n_streams)
-        return [q + (1 if i < r else 0) for i in range(n_streams)]
+        # ... for the models whose blocks run the fused LayerNorm+GEMM kernels (widths up to 384).  The MFMA-bound wide models lose with a third /
+        # fourth slice: ViT-B b512 35.5 k img/s at 256 + 256 against 34.8 k at 186 + 186 + 140, DeiT-B W4 39.3 k at 128 + 128 against 38.3 k
+        if batch < 16 * (n_streams + 1) or self.D > 384:       # (and small batches): a balanced split over the side streams only
+            q, r = divmod(batch, n_streams)
+            return [q + (1 if i < r else 0) for i in range(n_streams)]
+        d = 1000 * n_streams + 765                     # the caller's slice is ~0.77 of a side slice (52 : 68)
+        side = (batch * 1000 + d - 1) // d
+        return [side] * n_streams + [batch - n_streams * side]
 
     def forward_streams(self, images, bit_config, out, n_streams=3, slices=None):
         """Same result as ``forward``; the batch is cut into contiguous slices (``slice_sizes`` or an explicit list) that run on

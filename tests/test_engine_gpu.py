@@ -165,7 +165,11 @@ def test_deit_small_full_batch_properties(dva, oracle, synth):
     one = plan.forward(x, bits).cpu()
     assert torch.equal(one, o)                                      # one stream == two streams
     out3 = torch.empty(256, 1000, device='cuda')
-    plan.forward_streams(x, bits, out3)                             # the default: three balanced slices (86 + 85 + 85 images)
+    plan.forward_streams(x, bits, out3)                             # the default: 68 + 68 + 68 images on three side streams, 52 on the caller's
+    assert torch.equal(out3.cpu(), o)
+    assert plan.slice_sizes(256, 3) == [68, 68, 68, 52] and plan.slice_sizes(63, 3) == [21, 21, 21] and plan.slice_sizes(5, 3) == [5]
+    assert plan.D <= 384                                             # (wider models keep the balanced split over the side streams: 256 + 256)
+    plan.forward_streams(x, bits, out3.zero_(), 3, [86, 85, 85])
     assert torch.equal(out3.cpu(), o)
     assert torch.equal(plan.forward(x[:255], bits).cpu(), o[:255])
     assert len(set(o[:32].argmax(1).tolist())) > 3
@@ -840,6 +844,23 @@ def test_other_configs_engine_vs_oracle(dva, oracle, name, bits):
         ref = orc.quant_forward(x, bc)
         assert torch.equal(out.cpu(), ref), (name, bc[:6], int((out.cpu() != ref).sum()))
         assert flops == orc.flops()
+    # ... and at BASELINE's full batch (config 3: ViT-B at 512, config 5: DeiT-B W4 at 256), through a size-independent property: images are
+    # independent, so the oracle-verified images keep their logits wherever they sit in a full batch, on one stream and on the two slice
+    # streams of the bench (the 256-row GEMM tiles and every multi-round grid of the full size are exercised; 0.3 s)
+    full = {'vit_base': 512, 'deit_base': 256}.get(name)
+    if full:
+        big = dva.synth.images(77, 32, 224).repeat(full // 32, 1, 1, 1)
+        pos = [0, full // 2 - 1, full - 1][:x.shape[0]]
+        for i, p_ in enumerate(pos):
+            big[p_] = x[i]
+        plan = m._plan
+        bc = cfgs[0]
+        for streams in (1, 2):
+            lg = torch.empty(full, arch['num_classes'], device='cuda')
+            plan.forward_streams(big.cuda(), bc, lg, streams)
+            torch.cuda.synchronize()
+            assert torch.equal(lg[pos].cpu(), orc.quant_forward(x, bc)), (name, streams)
+            assert torch.equal(lg[1].cpu(), lg[33].cpu())                      # the same image at two positions of the batch
 
 
 @pytest.mark.parametrize('img,patch,dim,depth,heads', [(384, 16, 128, 2, 2), (96, 8, 64, 2, 2), (160, 16, 128, 2, 4),
@@ -1087,6 +1108,15 @@ def test_swin_base_engine_vs_oracle(dva, oracle):
         torch.cuda.synchronize()
         ref = SO.OracleSwin(m.arch, {k: v.cpu() for k, v in m.state_dict().items()}).quant_forward(x, m.export_calib(), 8)
     assert torch.equal(out.cpu(), ref), int((out.cpu() != ref).sum())
+    # BASELINE config 4 at its per-GPU batch of 256 (global 2048 over DP = 8): the two oracle-verified images keep their logits wherever they sit
+    # in the full batch, which runs as the bench runs it (two slices on two streams)
+    big = S.images(78, 32, 224).repeat(8, 1, 1, 1)
+    big[0], big[255] = x[0], x[1]
+    with torch.no_grad():
+        lg = m._plan.forward(big.cuda(), n_streams=2)
+        torch.cuda.synchronize()
+    assert torch.equal(lg[[0, 255]].cpu(), ref)
+    assert torch.equal(lg[1].cpu(), lg[33].cpu())
 
 
 def test_swin_tiny_k96_engine_vs_oracle(dva, oracle):
