@@ -76,7 +76,8 @@ def bench_swin(args, dva, dev, world, rank):
     B = args.batch
     x = base.repeat((B + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:B].contiguous().to(dev)
     dist = args.dist
-    runner = dva.dp.DataParallelForward(lambda xs: plan.forward(xs, n_streams=args.streams), arch['num_classes'], always_gather=args.force_dist)
+    sw_slices = [int(v) for v in args.slices.split(',')] if args.slices else None
+    runner = dva.dp.DataParallelForward(lambda xs: plan.forward(xs, n_streams=args.streams, slices=sw_slices), arch['num_classes'], always_gather=args.force_dist)
     out, gat = [None], [None]
 
     def step():
@@ -88,8 +89,8 @@ def bench_swin(args, dva, dev, world, rank):
     times = timed_repeats(step, args.steps, args.repeats, world, dev, dist)
     el = times[len(times) // 2]
     # roofline of the dominant op kind: one launch = one stream slice, timed by p2v_run_ops_profile (HIP events on the launch stream)
-    n_sl = args.streams if (args.streams > 1 and B >= 16 * args.streams) else 1
-    Bl = (B + n_sl - 1) // n_sl
+    n_sl = len(sw_slices) if sw_slices else (args.streams if (args.streams > 1 and B >= 16 * args.streams) else 1)
+    Bl = max(sw_slices) if sw_slices else (B + n_sl - 1) // n_sl
     prof = plan.profile(x[:Bl])
     prof = plan.profile(x[:Bl])
     rec = plan._recorded[(Bl, 0, True)]

@@ -372,24 +372,35 @@ class SwinPlan:
             raise AssertionError("Input image size (%d*%d) doesn't match model (%d*%d)." % (images.shape[2], images.shape[3], a['img_size'], a['img_size']))
         return images
 
-    def forward(self, images, taps=None, n_streams=2):
+    def forward(self, images, taps=None, n_streams=3, slices=None):
         """images fp32 [B, in_chans, S, S] on the plan's device -> logits fp32 [B, classes] (act_out grid).  One C call replays
         the recorded launch sequence; a large batch runs as ``n_streams`` contiguous slices on their own HIP streams (images are
-        independent), like the ViT plan."""
+        independent), like the ViT plan (three: Swin-B at 256 images 25.1 k img/s against 24.6 k on two, same call, profiles/r04_slices.txt).
+        ``slices``: explicit slice sizes; slices beyond ``n_streams`` run on the caller's stream."""
         images = self._check_images(images)
         B = images.shape[0]
-        if taps is not None or n_streams <= 1 or B < 16 * n_streams:
+        if taps is not None or n_streams <= 1 or (slices is None and B < 16 * n_streams):
             return self._replay(images, 0, taps)
+        if slices is None:
+            step = (B + n_streams - 1) // n_streams
+            slices = [min(step, B - i * step) for i in range(n_streams) if i * step < B]
+        if sum(slices) != B or min(slices) < 1:
+            raise AssertionError('slices %r do not cover a batch of %d' % (list(slices), B))
         if getattr(self, '_streams', None) is None or len(self._streams) != n_streams:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         cur = torch.cuda.current_stream(self.device)
-        step = (B + n_streams - 1) // n_streams
-        outs = []
-        for i, st in enumerate(self._streams):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                outs.append(self._replay(images[i * step:(i + 1) * step], i + 1))
-        for st in self._streams:
+        outs, lo = [], 0
+        for i, n_i in enumerate(slices):
+            xi = images[lo:lo + n_i]
+            lo += n_i
+            if i < n_streams:
+                st = self._streams[i]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    outs.append(self._replay(xi, i + 1))
+            else:                                      # the caller's own stream (slot 0: the single-stream record of that batch size)
+                outs.append(self._replay(xi, 0))
+        for st in self._streams[:min(n_streams, len(slices))]:
             cur.wait_stream(st)
         for o in outs:
             o.record_stream(cur)

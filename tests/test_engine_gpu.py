@@ -1109,11 +1109,11 @@ def test_swin_base_engine_vs_oracle(dva, oracle):
         ref = SO.OracleSwin(m.arch, {k: v.cpu() for k, v in m.state_dict().items()}).quant_forward(x, m.export_calib(), 8)
     assert torch.equal(out.cpu(), ref), int((out.cpu() != ref).sum())
     # BASELINE config 4 at its per-GPU batch of 256 (global 2048 over DP = 8): the two oracle-verified images keep their logits wherever they sit
-    # in the full batch, which runs as the bench runs it (two slices on two streams)
+    # in the full batch, which runs as the bench runs it (three slices on three streams)
     big = S.images(78, 32, 224).repeat(8, 1, 1, 1)
     big[0], big[255] = x[0], x[1]
     with torch.no_grad():
-        lg = m._plan.forward(big.cuda(), n_streams=2)
+        lg = m._plan.forward(big.cuda())                  # (three slices on three streams, the default)
         torch.cuda.synchronize()
     assert torch.equal(lg[[0, 255]].cpu(), ref)
     assert torch.equal(lg[1].cpu(), lg[33].cpu())
@@ -1167,7 +1167,8 @@ def test_plan_file_roundtrip(dva, micro, tmp_path):
 
 
 def test_swin_batch_independence_and_stream_slices(dva):
-    """a 33-image batch (two stream slices of 17 + 16, recorded op lists per slice) gives the rows a 1-image and a 5-image call give."""
+    """a 33-image batch as two stream slices of 17 + 16 (recorded op lists per slice), as explicit slices with one on the caller's stream, and on
+    one stream gives the rows a 1-image and a 5-image call give."""
     m, _ = _micro_swin(dva)
     x = dva.synth.images(12, 33, 56)
     with torch.no_grad():
@@ -1175,12 +1176,18 @@ def test_swin_batch_independence_and_stream_slices(dva):
         m.model_quant()
         m.cuda()
         xc = x.cuda()
-        full = m(xc).cpu()
+        m(xc[:1])                                                   # freezes the plan
+        full = m._plan.forward(xc, n_streams=2).cpu()
         one = m(xc[20:21]).cpu()
         five = m(xc[28:33]).cpu()
         single_stream = m._plan.forward(xc, n_streams=1).cpu()
+        three = m._plan.forward(xc, n_streams=2, slices=[12, 12, 9]).cpu()          # the third slice on the caller's stream
+        default = m(xc).cpu()
     assert full.shape == (33, 10)
     assert torch.equal(full[20:21], one) and torch.equal(full[28:33], five) and torch.equal(full, single_stream)
+    assert torch.equal(three, full) and torch.equal(default, full)
+    with pytest.raises(AssertionError):
+        m._plan.forward(xc, n_streams=2, slices=[12, 12])
     with pytest.raises(AssertionError):
         m(torch.zeros(2, 3, 64, 64, device='cuda'))
     with pytest.raises(RuntimeError):

@@ -24,7 +24,7 @@ if [ -n "$OTHER_MODELS" ]; then
   cd $R
   python bench.py --model vit_base --batch 512 --streams 2 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${TAG}_cfg3_vit_base_b512.json 2>/dev/null
   python bench.py --model deit_base --bits 4 --batch 256 --streams 2 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${TAG}_cfg5_deit_base_w4.json 2>/dev/null
-  python bench.py --model swin_base --batch 256 --streams 2 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${TAG}_cfg4_swin_base.json 2>/dev/null
+  python bench.py --model swin_base --batch 256 --streams 3 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/${TAG}_cfg4_swin_base.json 2>/dev/null
   for f in cfg3_vit_base_b512 cfg5_deit_base_w4 cfg4_swin_base; do python -c "
 import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1], d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'])" gpurun_out/${TAG}_$f.json; done
   cd /tmp
