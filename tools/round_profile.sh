@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_tra
 cp $R/gpurun_out/${TAG}_trace/*/*kernel_stats.csv $R/gpurun_out/${TAG}_kernel_stats.csv
 head -12 $R/gpurun_out/${TAG}_kernel_stats.csv | cut -c1-150
 rm -rf $R/gpurun_out/${TAG}_trace      # the raw trace is tens of MB; only the summary is kept
-PMC_BATCH=86 bash $R/tools/pmc.sh > $R/gpurun_out/${TAG}_pmc.log 2>&1
+PMC_BATCH=68 bash $R/tools/pmc.sh > $R/gpurun_out/${TAG}_pmc.log 2>&1
 python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc > $R/gpurun_out/${TAG}_pmc_summary.txt
 cp $R/gpurun_out/pmc/summary.json $R/gpurun_out/${TAG}_pmc_summary.json
 rm -rf $R/gpurun_out/pmc
