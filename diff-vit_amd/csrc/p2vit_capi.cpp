@@ -224,7 +224,12 @@ int p2v_plan_set_linear(p2v_plan* plan, int layer, int bits, const p2v_linear* l
   plan->lin_set[bi][layer] = 1;
   if (layer >= 1 && layer < plan->n_layers - 1 && ((layer - 1) & 1)) {         // proj / fc2 of block (layer - 1) / 4: their RESID tables depend on these constants
     const int block = (layer - 1) / 4;
-    if (plan->block_set[block]) build_resid_tables(plan, block);
+    if (plan->block_set[block]) {
+      char keep[sizeof g_err];
+      memcpy(keep, g_err, sizeof keep);
+      build_resid_tables(plan, block);        // unusable tables simply leave the generic RESID epilogue in place
+      memcpy(g_err, keep, sizeof keep);
+    }
   }
   return P2V_OK;
 }

@@ -322,7 +322,7 @@ class FrozenPlan:
 
     def forward_streams(self, images, bit_config, out, n_streams=3, slices=None):
         """Same result as ``forward``; the batch is cut into contiguous slices (``slice_sizes`` or an explicit list) that run on
-        their own HIP streams with their own workspaces (a slice beyond ``n_streams`` runs on the caller's stream).  Images are
+        their own workspaces, round robin over ``n_streams`` side HIP streams and the caller's own stream (the slice after the side streams' runs there).  Images are
         independent, so this is only a scheduling choice: kernels of one slice (e.g. a VALU-bound GELU epilogue) overlap latency-
         or MFMA-bound phases of another slice's kernels."""
         images, cfg = self._check(images, bit_config)
@@ -346,11 +346,12 @@ class FrozenPlan:
             lo = hi = 0
             for i, n_i in enumerate(sizes):
                 lo, hi = hi, hi + n_i
-                st = self._streams[i] if i < n_side else cur        # slices beyond the side streams: the caller's stream
+                j = i % (n_side + 1)                                 # round robin over the side streams and the caller's stream
+                st = self._streams[j] if j < n_side else cur
                 n = L.p2v_workspace_bytes(self._handle, n_i)
                 if self._ws_multi[i] is None or self._ws_multi[i].numel() < n:
                     self._ws_multi[i] = torch.empty(n, dtype=torch.uint8, device=self.device)
-                if st is not cur:
+                if st is not cur and st not in used:
                     st.wait_stream(cur)
                     used.append(st)
                 xi, oi = images[lo:hi], out[lo:hi]
@@ -404,7 +405,8 @@ class FrozenPlan:
                     tokens.append(row)
                     for i, n_i in enumerate(sizes):
                         lo, hi = hi, hi + n_i
-                        st = self._streams[i] if i < n_side else cur
+                        j = i % (n_side + 1)
+                        st = self._streams[j] if j < n_side else cur
                         tok = C.c_void_p()
                         E.check(L.p2v_forward_profile_begin(self._handle, E.ptr(images[lo:hi]), n_i, cfg, len(bit_config), E.ptr(out[lo:hi]),
                                                             E.ptr(self._ws_multi[i]), self._ws_multi[i].numel(), C.c_void_p(st.cuda_stream), C.byref(tok)))
