@@ -338,7 +338,29 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
   __shared__ __attribute__((aligned(16))) int sM[NCH * LANES * 4];
   const int tid = threadIdx.x, l32 = tid & (LANES - 1), hw = tid / LANES;   // l32: lane within the row group
   LnLane<NCH, LN_LDSC> L;
-  if constexpr (PRE) {      // only post_mul and the mask go through LDS (LN_LDSC), one barrier
+  // A workgroup lives for only a few rows (16 - 32): its first rows are requested BEFORE the constants are staged, so that one memory round
+  // trip covers both (round 4; before, the row loads were issued behind the prologue's barrier: two exposed round trips per workgroup)
+  const int LN_ROWS = a.rows_per_half;
+  const long long row0 = ((long long)blockIdx.x * (256 / LANES) + hw) * LN_ROWS;
+  const long long last_row = a.rows - 1;
+  constexpr int R = LN_BATCH;                                      // rows per batch of ln_rows (the row scalars are computed once per batch)
+  int colofs[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) colofs[i] = (l32 + LANES * i) * 4 < a.C ? (l32 + LANES * i) * 4 : 0;     // clamped: loads are unconditional
+  unsigned wnext[R][NCH];
+#pragma unroll
+  for (int u = 0; u < R; ++u)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      wnext[u][i] = *reinterpret_cast<const unsigned*>(a.x + (row0 + u < a.rows ? row0 + u : last_row) * a.row_stride + colofs[i]);
+  if constexpr (PRE) {      // only post_mul and the mask go through LDS (LN_LDSC), one barrier; the folded constants are requested first
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (l32 + LANES * i) * 4;
+      L.on[i] = c < a.C;
+      L.gm[i] = *reinterpret_cast<const float4*>(a.pre.gm + c);
+      L.bt[i] = *reinterpret_cast<const float4*>(a.pre.bt + c);
+    }
     for (int t4 = tid; t4 < NCH * LANES; t4 += 256) {
       const int c = t4 * 4;
       float4 pmv = make_float4(0.f, 0.f, 0.f, 0.f), mk = pmv;
@@ -353,9 +375,6 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = (l32 + LANES * i) * 4;
-      L.on[i] = c < a.C;
-      L.gm[i] = *reinterpret_cast<const float4*>(a.pre.gm + c);
-      L.bt[i] = *reinterpret_cast<const float4*>(a.pre.bt + c);
       if constexpr (sizeof(L.pm) == sizeof(float4) * NCH) {
         L.pm[i] = *reinterpret_cast<const float4*>(sP + c);
         L.mkf[i] = *reinterpret_cast<const float4*>(sM + c);
@@ -372,22 +391,9 @@ __global__ __launch_bounds__(256) void k_int_layernorm(LnArgs a) {
   } else {
     ln_prepare<NCH, LANES>(a.ln, a.C, a.force_generic != 0, sG, sB, sP, sM, tid, 256, L);
   }
-  const int LN_ROWS = a.rows_per_half;
-  const long long row0 = ((long long)blockIdx.x * (256 / LANES) + hw) * LN_ROWS;
   // Row r+1 is requested at the top of the iteration of row r and first touched just before the stores of row r.  The two
   // empty asm statements pin that placement: left alone, hipcc sinks the loads of a loop-carried value to the loop end,
   // behind the stores, and waits vmcnt(0) there - two exposed memory round trips per row (measured: 3 us per row).
-  int colofs[NCH];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) colofs[i] = L.on[i] ? (l32 + LANES * i) * 4 : 0;     // clamped: loads are unconditional
-  const long long last_row = a.rows - 1;
-  constexpr int R = LN_BATCH;                                      // rows per batch of ln_rows (the row scalars are computed once per batch)
-  unsigned wnext[R][NCH];
-#pragma unroll
-  for (int u = 0; u < R; ++u)
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-      wnext[u][i] = *reinterpret_cast<const unsigned*>(a.x + (row0 + u < a.rows ? row0 + u : last_row) * a.row_stride + colofs[i]);
 #pragma unroll
   for (int u = 0; u < R; ++u)
 #pragma unroll
