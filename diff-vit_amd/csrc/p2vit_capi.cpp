@@ -254,6 +254,7 @@ struct OwnerDevice {
       (void)hipGetLastError();
       return;
     }
+    if (pa.type != hipMemoryTypeDevice && pa.type != hipMemoryTypeManaged) return;      // host memory (registered or not): not ours to launch on
     own = pa.device;
     if (own != prev && hipSetDevice(own) != hipSuccess) own = -1;
   }

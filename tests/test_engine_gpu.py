@@ -416,6 +416,8 @@ def test_gemm_resid_prefold_all_numerators(dva, oracle):
     u = C.c_int(7)
     assert L.p2v_resid_prefold(C.byref(lin), C.byref(epi), N, E.ptr(tab), 16, C.byref(u), None) == E.E_WORKSPACE and u.value == 0
     assert L.p2v_resid_prefold(C.byref(lin), C.byref(epi), N, None, 1 << 20, C.byref(u), None) == E.E_ARG
+    host = torch.empty(L.p2v_resid_prefold_bytes(N) // 4)                    # a HOST buffer is refused, not written to by a kernel
+    assert L.p2v_resid_prefold(C.byref(lin), C.byref(epi), N, E.ptr(host), host.numel() * 4, C.byref(u), None) == E.E_ARG and u.value == 0
 
 
 @pytest.mark.parametrize('C_,rows', [(64, 37), (192, 100), (384, 777), (768, 65), (1024, 9), (1536, 21), (2048, 35)])
