@@ -226,7 +226,9 @@ def main():
     ranks_seen = dist.get_world_size() if dist is not None else 1
     if ranks_seen != world:
         sys.exit('bench.py: WORLD_SIZE=%d but the process group has %d ranks' % (world, ranks_seen))
-    distinct = len({(d['host'], d['uuid'] or d['pci_bus_id'], d['local_device'] if not d['uuid'] else 0) for d in ident})
+    # two ranks share a device only if host, uuid, PCI address AND local index all coincide (a runtime that reports no uuid / PCI address still
+    # tells ranks apart by their local index; per-rank visibility masks by uuid / PCI address)
+    distinct = len({(d['host'], d['uuid'], d['pci_bus_id'], d['local_device']) for d in ident})
     if distinct < ranks_seen and not args.share_device:
         sys.exit('bench.py: %d ranks on %d distinct devices (%s): not an %d-GPU run' % (ranks_seen, distinct, ident, ranks_seen))
     args.identity = {'ranks_seen': ranks_seen, 'distinct_devices': distinct,
