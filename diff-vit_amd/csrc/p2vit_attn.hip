@@ -322,6 +322,7 @@ int p2v_launch_window_attention(const WinAttnArgs& a, hipStream_t st) {
 
 int p2v_launch_attention_wide(const AttnArgs& a, int head_dim, int nkb, hipStream_t st);      // p2vit_attn_wide.hip
 
+int g_attn_stream = 0;    // P2V_ATTN_STREAM=1: every launch takes the streaming kernel (parity runs against the resident one; same codes)
 int p2v_launch_attention(const AttnArgs& a, int head_dim, hipStream_t st) {
   const int nkb = (a.N + 31) / 32;
   {   // the kernel folds s_q1^2 / s_attn into qk_scale: exact only for a power of two (both are PoT scales in the reference)
@@ -329,6 +330,7 @@ int p2v_launch_attention(const AttnArgs& a, int head_dim, hipStream_t st) {
     const float m2 = a.at.s_qkv_sq * a.at.inv_s_attn;
     if (!(m2 > 0.f) || frexpf(m2, &ex) != 0.5f) return -2;
   }
+  if (g_attn_stream || a.N > p2v_resident_tokens_of(head_dim)) return p2v_launch_attention_stream(a, head_dim, st);
   if (head_dim == 64) { P2V_ATTN_CASES(64, 19, true) }
   if (head_dim == 32) { P2V_ATTN_CASES(32, 19, false) }
   return p2v_launch_attention_wide(a, head_dim, nkb, st);

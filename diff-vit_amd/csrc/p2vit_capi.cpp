@@ -117,6 +117,7 @@ extern int g_ln_gemm;
 extern int g_ln_gemm_ver;
 extern int g_gemm_tile;
 extern int g_resid_pre;
+extern int g_attn_stream;
 extern int g_ln_pre;
 // Tuning / A-B switches read once per process (first plan or first version query).  None of them changes results:
 // P2V_LN_GENERIC forces the generic LayerNorm chain (bit-identical to the fast one, both are tested).
@@ -132,6 +133,8 @@ static void read_env_once() {
   if (e && atoi(e) >= 1 && atoi(e) <= 3) g_ln_gemm_ver = atoi(e);
   e = getenv("P2V_GEMM_TILE");
   if (e && (atoi(e) == 0 || atoi(e) == 128 || atoi(e) == 256)) g_gemm_tile = atoi(e);
+  e = getenv("P2V_ATTN_STREAM");
+  if (e) g_attn_stream = atoi(e) != 0;
   e = getenv("P2V_LN_PRE");
   if (e) g_ln_pre = atoi(e) != 0;
   e = getenv("P2V_RESID_PRE");
@@ -143,12 +146,8 @@ static void read_env_once() {
 }
 int p2v_abi_version(void) { read_env_once(); return P2V_ABI_VERSION; }
 
-int p2v_max_tokens(int head_dim) {
-  if (head_dim == 32 || head_dim == 48 || head_dim == 64 || head_dim == 80) return P2V_MAX_TOKENS;
-  if (head_dim == 96) return 17 * 32;
-  if (head_dim == 128) return 12 * 32;
-  return 0;
-}
+int p2v_resident_tokens(int head_dim) { return p2v_resident_tokens_of(head_dim); }
+int p2v_max_tokens(int head_dim) { return p2v_resident_tokens_of(head_dim) ? P2V_MAX_TOKENS_STREAMED : 0; }
 
 int p2v_set_tuning(const char* name, int value) {
   if (!name) return fail(P2V_E_ARG, "p2v_set_tuning: null name");
@@ -160,6 +159,7 @@ int p2v_set_tuning(const char* name, int value) {
   if (!strcmp(name, "attn_waves") && value >= 4 && value <= 8) { g_attn_waves = value; return P2V_OK; }
   if (!strcmp(name, "resid_pre")) { g_resid_pre = value != 0; return P2V_OK; }
   if (!strcmp(name, "ln_pre")) { g_ln_pre = value != 0; return P2V_OK; }
+  if (!strcmp(name, "attn_stream")) { g_attn_stream = value != 0; return P2V_OK; }
   if (!strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) { g_gemm_tile = value; return P2V_OK; }
   return fail(P2V_E_ARG, "p2v_set_tuning: unknown switch or value out of range: %s = %d", name, value);
 }
@@ -179,13 +179,11 @@ int p2v_plan_create(const p2v_model_desc* desc, p2v_plan** out) {
   // rows are read in 16-byte pieces and stored 16 channels at a time; widths that are not multiples of the 64-deep k-tile run through zero
   // weight columns (the tile's last pieces then belong to the next row of the workspace buffer: multiplied by zero)
   if (d.embed_dim % 16 || d.mlp_hidden % 16) return fail(P2V_E_UNSUPPORTED, "embed_dim and mlp_hidden must be multiples of 16");
-  {   // the attention kernel keeps a query block's scores in registers and K / V^T of an image's head in LDS (3 * head_dim bytes per key):
-      // 608 tokens (19 key pairs) up to head_dim 80, 544 at 96, 384 at 128
+  {   // the resident attention kernel keeps a query block's scores in registers and K / V^T of an image's head in LDS (p2v_resident_tokens); the
+      // streaming kernel takes over beyond, up to 4096 tokens per image
     const int tokens = (d.img_size / d.patch_size) * (d.img_size / d.patch_size) + 1;
-    const int max_tokens = p2v_max_tokens(hd);
-    if (tokens > max_tokens)
-      return fail(P2V_E_UNSUPPORTED, "%d tokens per image at head_dim %d: the attention kernel covers up to %d (e.g. 384^2 / 16 = 577 at head_dim <= 80)", tokens,
-                  hd, max_tokens);
+    if (tokens > P2V_MAX_TOKENS_STREAMED)
+      return fail(P2V_E_UNSUPPORTED, "%d tokens per image: the attention kernels cover up to %d", tokens, P2V_MAX_TOKENS_STREAMED);
   }
   if (d.embed_dim > 2048) return fail(P2V_E_UNSUPPORTED, "embed_dim %d: the LayerNorm kernel covers up to 2048 channels", d.embed_dim);
   p2v_plan* p = new p2v_plan();

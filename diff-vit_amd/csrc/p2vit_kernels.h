@@ -76,6 +76,12 @@ int p2v_launch_layernorm(const LnArgs& a, hipStream_t st);
 bool p2v_ln_gemm_supported(int epi, int C, int N, int table_cells);
 int p2v_launch_ln_gemm(int epi, const LnArgs& a, const GemmArgs& g, hipStream_t st);   // -3: shape not fused
 int p2v_launch_attention(const AttnArgs& a, int head_dim, hipStream_t st);
+int p2v_launch_attention_stream(const AttnArgs& a, int head_dim, hipStream_t st);   // any token count up to P2V_MAX_TOKENS_STREAMED (p2vit_attn_stream.hip)
+// tokens per image the resident attention kernel covers (K / V^T of a head in LDS: 3 * head_dim bytes per key); 0: head_dim not instantiated
+inline int p2v_resident_tokens_of(int head_dim) {
+  if (head_dim == 32 || head_dim == 48 || head_dim == 64 || head_dim == 80) return P2V_MAX_TOKENS;
+  return head_dim == 96 ? 17 * 32 : (head_dim == 128 ? 12 * 32 : 0);
+}
 int p2v_launch_fake_quant(const float* x, long long n, const float* scale, int n_scale, long long inner, int lo, int hi,
                           float* out, int8_t* codes, hipStream_t st);
 int p2v_launch_gelu_quant(const float* y, long long n, float inv_s, int8_t* codes, unsigned long long* flags, int force_slow,

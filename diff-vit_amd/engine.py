@@ -109,6 +109,7 @@ def lib():
     L.p2v_ln_prefold_bytes.restype = C.c_size_t
     L.p2v_ln_prefold.argtypes = [C.POINTER(Ln), _i, _p, C.c_size_t]
     L.p2v_max_tokens.argtypes = [_i]
+    L.p2v_resident_tokens.argtypes = [_i]
     L.p2v_resid_prefold_bytes.argtypes = [_i]
     L.p2v_resid_prefold_bytes.restype = C.c_size_t
     L.p2v_resid_prefold.argtypes = [C.POINTER(Linear), C.POINTER(Epilogue), _i, _p, C.c_size_t, C.POINTER(_i), _p]

@@ -20,9 +20,10 @@
  *     per-channel PTF scales (ptf.py:51,133) are arbitrary fp32 and are divided by, as the reference does.
  *
  * Limits of what is instantiated (everything else returns P2V_E_UNSUPPORTED, at plan creation where the geometry is known):
- *   - ViT attention: head_dim 32, 48, 64, 80, 96 or 128 (round 4; before: 32 / 64); up to P2V_MAX_TOKENS = 608 tokens per image
- *     (224^2 / 16 = 197, 384^2 / 16 = 577, ...) - 544 at head_dim 96 and 384 at head_dim 128, where K / V^T of an image's head fill the LDS:
- *     p2v_max_tokens(head_dim);
+ *   - ViT attention: head_dim 32, 48, 64, 80, 96 or 128 (round 4; before: 32 / 64); up to P2V_MAX_TOKENS_STREAMED = 4096 tokens per image.  The
+ *     fast kernel keeps K / V^T of an image's head in LDS: P2V_MAX_TOKENS = 608 tokens (224^2 / 16 = 197, 384^2 / 16 = 577, ...), 544 at head_dim 96,
+ *     384 at head_dim 128 (p2v_resident_tokens); beyond, a streaming kernel re-reads K / V per query block (round 4: slow, exact, so that no
+ *     geometry of the reference's VisionTransformer is refused; 448^2 / 16 = 785, 512^2 / 16 = 1025);
  *     Swin window attention: head_dim 32, windows up to 8 x 8;
  *   - embed_dim and MLP width of a plan: multiples of 16 (round 4; before: 64) - the contractions walk 64-deep k-tiles through zero weight
  *     columns (p2v_linear: k_pad = round_up(K, 64)); the per-operator GEMM entry points take K in whole k-tiles;
@@ -43,9 +44,12 @@ extern "C" {
 #endif
 
 #define P2V_ABI_VERSION 5
-#define P2V_MAX_TOKENS 608   /* tokens per image of the ViT attention kernel (19 pairs of 32 keys) */
-/* tokens per image the attention kernel covers at this head dimension (0: head_dim not instantiated) */
+#define P2V_MAX_TOKENS 608            /* tokens per image of the RESIDENT ViT attention kernel (K / V^T of a head in LDS; 19 pairs of 32 keys) */
+#define P2V_MAX_TOKENS_STREAMED 4096  /* tokens per image of the streaming attention kernel that takes over beyond the resident one's limit (round 4) */
+/* tokens per image a plan / p2v_lis_attention accepts at this head dimension (P2V_MAX_TOKENS_STREAMED; 0: head_dim not instantiated), and how many of
+ * them the resident (fast) kernel covers: 608 up to head_dim 80, 544 at 96, 384 at 128 - launches beyond run the streaming kernel */
 int p2v_max_tokens(int head_dim);
+int p2v_resident_tokens(int head_dim);
 
 enum {
   P2V_OK = 0,

@@ -113,13 +113,15 @@ def test_module_cache_follows_replaced_submodules():
 
 
 def test_head_dims_and_token_limits():
-    """what p2v_plan_create accepts: head_dim 32 / 48 / 64 / 80 / 96 / 128 with the token limit of each (K / V^T of a head stay in LDS)."""
+    """what p2v_plan_create accepts: head_dim 32 / 48 / 64 / 80 / 96 / 128, up to 4096 tokens per image (the resident attention kernel covers 608 / 544 / 384
+    of them, the streaming kernel the rest)."""
     import diff_vit_amd
     E = diff_vit_amd.engine
     L = E.lib()
-    assert [L.p2v_max_tokens(h) for h in (32, 48, 64, 80, 96, 128, 16, 112, 160)] == [608, 608, 608, 608, 544, 384, 0, 0, 0]
+    assert [L.p2v_resident_tokens(h) for h in (32, 48, 64, 80, 96, 128, 16, 112, 160)] == [608, 608, 608, 608, 544, 384, 0, 0, 0]
+    assert [L.p2v_max_tokens(h) for h in (32, 48, 64, 80, 96, 128, 16, 112, 160)] == [4096] * 6 + [0, 0, 0]
     import ctypes
-    for dim, heads, img, ok in ((256, 2, 224, True), (256, 2, 320, False), (192, 2, 224, True), (192, 2, 384, False), (320, 4, 384, True),
+    for dim, heads, img, ok in ((256, 2, 224, True), (256, 2, 320, True), (192, 2, 224, True), (192, 2, 384, True), (320, 4, 384, True), (128, 2, 1040, False),
                                 (192, 4, 384, True), (224 * 2, 4, 224, False), (64, 4, 224, False), (160, 2, 224, True), (144, 3, 224, True), (200, 5, 224, False)):
         h = ctypes.c_void_p()
         d = E.ModelDesc(E.P2V_ABI_VERSION, img, 16, 3, dim, 1, heads, 4 * dim, 10)

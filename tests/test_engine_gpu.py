@@ -556,6 +556,30 @@ def test_ln_gemm_fused_vs_separate_and_oracle(dva, oracle, C_, N, M, kind, table
                                           (2, 197, 2, 128, 4), (1, 384, 1, 128, 5), (1, 33, 2, 128, 4), (2, 197, 3, 96, 4), (1, 544, 1, 96, 5),
                                           (2, 197, 2, 80, 4), (1, 577, 1, 80, 5), (2, 50, 2, 48, 4), (1, 608, 1, 48, 4)])
 def test_lis_attention(dva, oracle, B, N, H, hd, e_at):
+    _check_lis_attention(dva, oracle, B, N, H, hd, e_at)
+
+
+@pytest.mark.parametrize('B,N,H,hd,e_at', [(1, 609, 2, 64, 4), (1, 785, 1, 64, 5), (1, 1025, 1, 64, 4), (2, 577, 1, 128, 4), (1, 600, 1, 96, 5),
+                                          (1, 700, 2, 32, 4), (1, 650, 1, 80, 4), (1, 620, 1, 48, 4)])
+def test_lis_attention_streamed(dva, oracle, B, N, H, hd, e_at):
+    """token counts beyond what the resident kernel holds in LDS (608; 544 / 384 at head_dim 96 / 128) run the streaming kernel (round 4:
+    448^2 / 16 = 785, 512^2 / 16 = 1025 tokens ...): every softmax exponent and every output code against the oracle."""
+    assert N > dva.engine.lib().p2v_resident_tokens(hd) > 0
+    _check_lis_attention(dva, oracle, B, N, H, hd, e_at)
+
+
+@pytest.mark.parametrize('B,N,H,hd,e_at', [(2, 197, 3, 64, 4), (3, 49, 4, 32, 5), (1, 224, 2, 64, 4), (1, 1, 1, 32, 4), (2, 197, 2, 128, 4), (1, 209, 1, 80, 5)])
+def test_lis_attention_streamed_equals_resident(dva, oracle, B, N, H, hd, e_at):
+    """... and where both kernels apply they give the same bytes: the streaming kernel forced by the switch (P2V_ATTN_STREAM / "attn_stream")."""
+    L = dva.engine.lib()
+    assert L.p2v_set_tuning(b'attn_stream', 1) == 0
+    try:
+        _check_lis_attention(dva, oracle, B, N, H, hd, e_at)
+    finally:
+        L.p2v_set_tuning(b'attn_stream', 0)
+
+
+def _check_lis_attention(dva, oracle, B, N, H, hd, e_at):
     E, S = dva.engine, dva.synth
     D = H * hd
     qkv = _rand_codes(S, 4, 'aq%d' % N, (B, N, 3 * D), 30.0)
@@ -869,7 +893,9 @@ def test_other_configs_engine_vs_oracle(dva, oracle, name, bits):
                                                        # head_dim 128 / 96 / 80 / 48 (round 4; vit_fquant.py:108: any dim // num_heads)
                                                        (160, 16, 256, 2, 2), (96, 8, 192, 2, 2), (96, 8, 320, 1, 4), (64, 8, 192, 2, 4),
                                                        # widths that are not multiples of the 64-deep k-tile (round 4): 160 = 2 x 80, 144 = 3 x 48
-                                                       (96, 8, 160, 2, 2), (64, 8, 144, 2, 3)])
+                                                       (96, 8, 160, 2, 2), (64, 8, 144, 2, 3),
+                                                       # 677 tokens (416^2 / 16): beyond the resident attention kernel - the streaming kernel (round 4)
+                                                       (416, 16, 128, 1, 2)])
 def test_other_token_counts_engine_vs_oracle(dva, oracle, img, patch, dim, depth, heads):
     """VisionTransformer takes any img_size (vit_fquant.py:494,535-540): 384^2 / 16 = 577 tokens (the 384-pixel ViT / DeiT variants), 145 and
     101 tokens, and head dimensions 32 ... 128: the whole quantized forward through the drop-in surface equals the oracle on every logit;
@@ -894,8 +920,11 @@ def test_other_token_counts_engine_vs_oracle(dva, oracle, img, patch, dim, depth
         big = dva.VisionTransformer(img_size=400, patch_size=16, embed_dim=dim, depth=1, num_heads=heads, num_classes=10, mlp_ratio=4.0, qkv_bias=True,
                                     norm_layer=partial(dva.QIntLayerNorm, eps=1e-6), input_quant=True, cfg=dva.Config()).cuda().eval()
         dva.harness.calibrate_model(big, dva.synth.images(33, 1, 400).cuda())
-        with pytest.raises(NotImplementedError):          # 626 tokens: P2V_MAX_TOKENS = 608
-            big(dva.synth.images(33, 1, 400).cuda(), [8] * 6)
+        with pytest.raises(NotImplementedError):          # 4226 tokens: P2V_MAX_TOKENS_STREAMED = 4096
+            dva.engine.check(dva.engine.lib().p2v_plan_create(C.byref(dva.engine.ModelDesc(dva.engine.P2V_ABI_VERSION, 1040, 16, 3, dim, 1, heads, 4 * dim, 10)),
+                                                              C.byref(C.c_void_p())))
+        out_big = big(dva.synth.images(33, 1, 400).cuda(), [8] * 6)[0]        # 626 tokens run (streaming attention)
+        assert out_big.shape == (1, 10) and torch.isfinite(out_big).all()
 
 
 def test_fp_input_model_engine_vs_reference_golden(dva, oracle, synth):
