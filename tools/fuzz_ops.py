@@ -119,7 +119,7 @@ def attn_case(i):
     global fails
     hd = [32, 64, 48, 80, 96, 128][i % 6]             # every instantiated head dimension (two 64-deep MFMA steps per score from 80 on)
     H = int(torch.randint(1, 5, (1,), generator=g))
-    N = [197, 50, 17, 33, 64][i % 5]
+    N = [197, 50, 17, 33, 64, 650, 401][i % 7]      # 650 (and 401 at head_dim 128): beyond the resident kernel - the streaming one
     B = int(torch.randint(1, 4, (1,), generator=g))
     D = H * hd
     qkv = torch.clamp(torch.round(rnd(B, N, 3 * D, std=float(torch.rand(1, generator=g)) * 70 + 0.5)), -128, 127)
