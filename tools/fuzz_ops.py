@@ -8,6 +8,7 @@ E = dva.engine
 L = E.lib()
 g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 fails = 0
+stats = {'resid_tables': 0, 'resid_tables_usable': 0}
 
 
 def rnd(*shape, std=1.0):
@@ -43,7 +44,16 @@ def ln_case(i):
     out = torch.zeros(rows, C_, dtype=torch.int8, device='cuda')
     E.check(L.p2v_int_layernorm(E.ptr(dev[0]), C_, rows, C_, C.byref(lnp), E.ptr(out), C_, E.stream_ptr()))
     got = out.cpu().float()
+    # the same launch on constants folded ahead of it (p2v_ln_prefold, round 4): identical codes whatever the parameters
+    nb = L.p2v_ln_prefold_bytes(C_)
+    buf = torch.empty(nb // 4, dtype=torch.float32, device='cuda')
+    E.check(L.p2v_ln_prefold(C.byref(lnp), C_, E.ptr(buf), nb))
+    out2 = torch.zeros(rows, C_, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_int_layernorm(E.ptr(dev[0]), C_, rows, C_, C.byref(lnp), E.ptr(out2), C_, E.stream_ptr()))
     finite = torch.isfinite(ln[0]).all(dim=1)            # rows with std == 0 give inf/nan in the reference: not compared
+    if not torch.equal(out2.cpu()[finite], out.cpu()[finite]):
+        fails += 1
+        print('LN case %d C=%d rows=%d: pre-folded constants give %d other codes' % (i, C_, rows, int((out2.cpu()[finite] != out.cpu()[finite]).sum())))
     bad = int((got[finite] != ref[finite]).sum())
     if bad and i % 7 == 0 and i % 2 == 0:
         # non power-of-two output scale: the ABI takes 1/out_scale and multiplies where the reference divides (exact only for
@@ -113,6 +123,15 @@ def ln_gemm_case(i):
     if bad:
         fails += 1
         print('LN+GEMM case %d C=%d N=%d M=%d kind=%d: %d mismatches' % (i, C_, N, M, kind, bad))
+    # ... and on LayerNorm constants folded ahead of the launch (p2v_ln_prefold): the same codes
+    nb = L.p2v_ln_prefold_bytes(C_)
+    buf = torch.empty(nb // 4, dtype=torch.float32, device='cuda')
+    E.check(L.p2v_ln_prefold(C.byref(lnp), C_, E.ptr(buf), nb))
+    out2 = torch.zeros(M, N, dtype=torch.int8, device='cuda')
+    E.check(L.p2v_ln_gemm_i8(kind, E.ptr(d[0]), C_, M, C_, C.byref(lnp), N, C.byref(lin), C.byref(epi), E.ptr(out2), N, None, E.stream_ptr()))
+    if not torch.equal(out2[finite], out_f[finite]):
+        fails += 1
+        print('LN+GEMM case %d C=%d N=%d M=%d kind=%d: pre-folded LayerNorm constants give %d other codes' % (i, C_, N, M, kind, int((out2[finite] != out_f[finite]).sum())))
 
 
 def attn_case(i):
@@ -193,6 +212,21 @@ def gemm_case(i):
     if bad:
         fails += 1
         print('gemm RESID case %d M=%d K=%d N=%d: %d mismatches' % (i, M, K, N, bad))
+    # the same launch on the constants of p2v_resid_prefold (round 4): when the device certifies the table, identical codes
+    nb = L.p2v_resid_prefold_bytes(N)
+    tab = torch.empty(nb // 4, dtype=torch.float32, device='cuda')
+    usable = C.c_int(-1)
+    E.check(L.p2v_resid_prefold(C.byref(lin), C.byref(epi), N, E.ptr(tab), nb, C.byref(usable), None))
+    stats['resid_tables'] += 1
+    if usable.value == 1:
+        stats['resid_tables_usable'] += 1
+        epi.resid_tab = E.ptr(tab)
+        out2 = torch.zeros(M, N, dtype=torch.int8, device='cuda')
+        E.check(L.p2v_gemm_i8(E.EPI_RESID, E.ptr(dev[0]), K, M, K, N, C.byref(lin), C.byref(epi), E.ptr(out2), N, None, E.stream_ptr()))
+        bad = int((out2.cpu().float() != ref).sum())
+        if bad:
+            fails += 1
+            print('gemm RESID (pre-folded) case %d M=%d K=%d N=%d: %d mismatches' % (i, M, K, N, bad))
 
 
 def winattn_case(i):
@@ -259,5 +293,5 @@ for i in range(n):
     winattn_case(i)
     ln_gemm_case(i)
 torch.cuda.synchronize()
-print('fuzz: %d cases per op, %d failing' % (n, fails))
+print('fuzz: %d cases per op, %d failing; pre-folded RESID tables certified %d of %d' % (n, fails, stats['resid_tables_usable'], stats['resid_tables']))
 sys.exit(1 if fails else 0)
