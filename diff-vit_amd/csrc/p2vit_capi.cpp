@@ -729,6 +729,7 @@ int p2v_gemm_i8(int kind, const int8_t* A, int lda, int M, int K, int N, const p
   if (M <= 0 || N <= 0 || K <= 0 || K % GBK_PAD) return fail(P2V_E_SHAPE, "K=%d must be a positive multiple of %d", K, GBK_PAD);
   if (kind != P2V_EPI_HEAD && (N % 16 || ldo % 16)) return fail(P2V_E_UNSUPPORTED, "N and ldo must be multiples of 16 for int8 outputs");
   if (lda % 16) return fail(P2V_E_UNSUPPORTED, "lda must be a multiple of 16");
+  if (lda <= 0 || ldo < N) return fail(P2V_E_SHAPE, "p2v_gemm_i8: lda=%d must be positive and ldo=%d must cover the %d outputs of a row", lda, ldo, N);
   if (kind == P2V_EPI_REQUANT && check_requant_scale("p2v_gemm_i8", epi->inv_s_out) != P2V_OK) return P2V_E_UNSUPPORTED;
   if (kind == P2V_EPI_GELU && check_gelu_tab("p2v_gemm_i8", epi->gelu) != P2V_OK) return P2V_E_ARG;
   if (kind == P2V_EPI_RESID && (!epi->s_mid || !epi->s_res || !epi->s_next || !epi->residual)) return fail(P2V_E_ARG, "RESID epilogue needs s_mid/s_res/s_next/residual");
@@ -775,6 +776,7 @@ int p2v_int_layernorm(const int8_t* x, long long row_stride, int rows, int C, co
   if (!x || !ln || !out) return fail(P2V_E_ARG, "p2v_int_layernorm: null argument");
   if (C % 4 || row_stride % 4 || out_stride % 4) return fail(P2V_E_UNSUPPORTED, "C and strides must be multiples of 4");
   if (rows <= 0) return fail(P2V_E_SHAPE, "rows must be positive");
+  if (C <= 0 || row_stride < 0 || out_stride < C) return fail(P2V_E_SHAPE, "p2v_int_layernorm: C=%d must be positive, row_stride non-negative, out_stride >= C", C);
   LnArgs a{x, row_stride, rows, C, *ln, out, out_stride};
   a.pre = ln->pre;                       // optional: constants folded ahead of the launch (p2v_ln_prefold)
   return launch_rc(p2v_launch_layernorm(a, (hipStream_t)stream), "int_layernorm");
@@ -786,6 +788,7 @@ int p2v_ln_gemm_i8(int kind, const int8_t* x, long long row_stride, int M, int C
   if (kind != P2V_EPI_REQUANT && kind != P2V_EPI_GELU) return fail(P2V_E_ARG, "p2v_ln_gemm_i8: epilogue %d (REQUANT and GELU are fused)", kind);
   if (M <= 0 || C <= 0 || N <= 0) return fail(P2V_E_SHAPE, "p2v_ln_gemm_i8: bad shape");
   if (C % 4 || row_stride % 4 || N % 16 || ldo != N) return fail(P2V_E_UNSUPPORTED, "p2v_ln_gemm_i8: C, row_stride multiples of 4; N multiple of 16; ldo == N");
+  if (row_stride < 0) return fail(P2V_E_SHAPE, "p2v_ln_gemm_i8: negative row_stride");
   if (kind == P2V_EPI_REQUANT && check_requant_scale("p2v_ln_gemm_i8", epi->inv_s_out) != P2V_OK) return P2V_E_UNSUPPORTED;
   if (kind == P2V_EPI_GELU && check_gelu_tab("p2v_ln_gemm_i8", epi->gelu) != P2V_OK) return P2V_E_ARG;
   read_env_once();

@@ -307,12 +307,14 @@ int p2v_quantize_patchify(const float* img, int batch, int chans, int height, in
 
 /* out = epilogue(A[M][K] . W[N][K]^T): int8 MFMA (v_mfma_i32_32x32x32_i8), fp32 epilogue in the
  * reference's operation order.  lda/ldo in elements.  `out` is int8 [M][ldo] except HEAD (fp32 [M][ldo]);
- * when out_codes != NULL the HEAD epilogue also writes the int8 logit codes there ([M][ldo]). */
+ * when out_codes != NULL the HEAD epilogue also writes the int8 logit codes there ([M][ldo]).
+ * K is a multiple of 64 and MAY exceed lda (a width that is not a multiple of 64: the weight columns [width, K) are zero): the
+ * contraction then walks into the next row, so (M-1)*lda + K bytes of A must be readable.  ldo >= N.  P2V_E_SHAPE otherwise. */
 int p2v_gemm_i8(int epilogue_kind, const int8_t* A, int lda, int M, int K, int N, const p2v_linear* lin,
                 const p2v_epilogue* epi, void* out, int ldo, int8_t* out_codes, void* stream);
 
 /* rows x C int8 -> rows x C int8; row r of the input starts at x + r*row_stride (lets the final norm
- * touch only the cls rows, vit_fquant.py:766-767). */
+ * touch only the cls rows, vit_fquant.py:766-767).  C: a multiple of 4 up to 2048; out_stride >= C. */
 int p2v_int_layernorm(const int8_t* x, long long row_stride, int rows, int C, const p2v_ln* ln,
                       int8_t* out, long long out_stride, void* stream);
 

@@ -89,6 +89,49 @@ def test_bit_config_and_shape_errors(dva, micro):
         plan.forward_streams(torch.cat([x] * 4), [8] * 10, torch.empty(3, 10, device='cuda'))     # out of the wrong shape
 
 
+def test_operator_entry_points_refuse_bad_arguments(dva, oracle):
+    """the per-operator C entry points return an error code (and leave the outputs alone) instead of launching on arguments whose
+    rows would overlap or run past the buffers: the kernels index from these numbers without further checks."""
+    E = dva.engine
+    L = E.lib()
+    z = torch.zeros(4096, dtype=torch.int8, device='cuda')
+    f = torch.ones(256, device='cuda')
+    lin = E.Linear(E.ptr(z), E.ptr(f), E.ptr(f))
+    epi = E.Epilogue(); epi.inv_s_out = 16.0
+    out = torch.full((4096,), 55, dtype=torch.int8, device='cuda')
+    g = lambda kind, lda, M, K, N, ldo, A=z: L.p2v_gemm_i8(kind, E.ptr(A) if A is not None else None, lda, M, K, N, C.byref(lin), C.byref(epi),
+                                                          E.ptr(out), ldo, None, E.stream_ptr())
+    assert g(E.EPI_REQUANT, 64, 4, 64, 16, 16) == 0                            # the well-formed call
+    torch.cuda.synchronize()
+    out.fill_(55)
+    assert g(E.EPI_REQUANT, 64, 4, 64, 32, 16) == E.E_SHAPE                    # ldo < N: rows of the output would overlap
+    assert g(E.EPI_REQUANT, 0, 4, 64, 16, 16) == E.E_SHAPE
+    assert g(E.EPI_REQUANT, 64, 0, 64, 16, 16) == E.E_SHAPE
+    assert g(E.EPI_REQUANT, 64, 4, 96, 16, 16) == E.E_SHAPE                    # K not a multiple of 64
+    assert g(E.EPI_REQUANT, 64, 4, 64, 24, 32) == E.E_UNSUPPORTED              # N not a multiple of 16
+    assert g(E.EPI_REQUANT, 40, 4, 64, 16, 16) == E.E_UNSUPPORTED              # lda alignment
+    assert g(99, 64, 4, 64, 16, 16) == E.E_ARG
+    assert g(E.EPI_REQUANT, 64, 4, 64, 16, 16, A=None) == E.E_ARG
+    assert g(E.EPI_RESID, 64, 4, 64, 16, 16) == E.E_ARG                        # RESID without its scales / residual
+    lnp = E.Ln(0.01, E.ptr(f), E.ptr(f), E.ptr(f), E.ptr(f), E.ptr(f))
+    ln = lambda stride, rows, C_, ostride: L.p2v_int_layernorm(E.ptr(z), stride, rows, C_, C.byref(lnp), E.ptr(out), ostride, E.stream_ptr())
+    assert ln(64, 4, 64, 64) == 0
+    torch.cuda.synchronize()
+    out.fill_(55)
+    assert ln(64, 4, 64, 32) == E.E_SHAPE                                      # out_stride < C
+    assert ln(64, 0, 64, 64) == E.E_SHAPE
+    assert ln(64, 4, 0, 64) == E.E_SHAPE
+    assert ln(-64, 4, 64, 64) == E.E_SHAPE
+    assert ln(64, 4, 62, 64) == E.E_UNSUPPORTED
+    assert ln(64, 1, 4096, 4096) != 0                                          # beyond the instantiated widths
+    at = E.Attn(2.0 ** -8, 0.125, 16.0, 1.0, *oracle.lis_consts(torch.tensor([2.0 ** -4])))
+    assert L.p2v_lis_attention(E.ptr(z), 1, 0, 1, 64, C.byref(at), E.ptr(out), None, E.stream_ptr()) == E.E_SHAPE
+    assert L.p2v_lis_attention(E.ptr(z), 1, 4, 1, 40, C.byref(at), E.ptr(out), None, E.stream_ptr()) != 0       # head_dim not instantiated
+    assert L.p2v_lis_attention(E.ptr(z), 1, 5000, 1, 64, C.byref(at), E.ptr(out), None, E.stream_ptr()) != 0     # beyond p2v_max_tokens
+    torch.cuda.synchronize()
+    assert int((out != 55).sum()) == 0                                         # no refused call wrote anything
+
+
 # --------------------------------------------------------------------------------------------------
 # whole model, DeiT-S (BASELINE config 2 shape) vs the oracle with the reference's calibration state
 # --------------------------------------------------------------------------------------------------
