@@ -114,7 +114,7 @@ def bench_swin(args, dva, dev, world, rank):
             'repeats': args.repeats, 'ms_per_step_min_max': [round(times[0] / args.steps * 1e3, 3), round(times[-1] / args.steps * 1e3, 3)],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int8' if args.bits == 8 else 'int4w/int8a', 'data': 'synthetic',
             'config': {'workload': '%s PoT-PTQ forward, int%d weights, %dx%d, batch %d per GPU' % (args.model, args.bits, arch['img_size'], arch['img_size'], B),
-                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'streams_per_gpu': args.streams,
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'streams_per_gpu': args.streams, 'side_streams': dva.engine.SIDE_STREAM_REPORT.get(dev.index),
                        'collective': 'all_gather(logits)' if dist is not None else 'none', 'backend': args.backend if dist is not None else None,
                        **args.identity},
             'roofline': roof,
@@ -446,7 +446,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int%d' % args.bits if args.bits == 8 else 'int4w/int8a',
             'data': 'synthetic',
             'config': {'workload': args.model + ' PoT-PTQ forward, bit_config=[%d]*50, 224x224, batch %d per GPU' % (args.bits, B),
-                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'streams_per_gpu': args.streams, 'batch_slices': slices,
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'streams_per_gpu': args.streams, 'side_streams': dva.engine.SIDE_STREAM_REPORT.get(dev.index), 'batch_slices': slices,
                        'collective': 'all_gather(logits)' if dist is not None else 'none', 'backend': args.backend if dist is not None else None,
                        'gathered_logits_equal_per_rank_forwards': gather_ok, **args.identity},
             'roofline': roof,

@@ -918,6 +918,12 @@ int p2v_gelu_quant_f32(const float* y, long long n, float inv_s, int8_t* codes, 
   return launch_rc(p2v_launch_gelu_quant(y, n, inv_s, codes, flags, force_slow, (hipStream_t)stream), "gelu_quant");
 }
 
+int p2v_stream_probe(void* stream, int kernels, int usec, int workgroups, int lds_bytes) {
+  if (kernels < 1 || kernels > 64 || usec < 1 || usec > 1000 || workgroups < 1 || workgroups > 4096 || lds_bytes < 0 || lds_bytes > 65536)
+    return fail(P2V_E_ARG, "p2v_stream_probe: 1..64 kernels of 1..1000 us, 1..4096 workgroups, 0..64 KB of LDS");
+  return launch_rc(p2v_launch_stream_probe(kernels, usec, workgroups, lds_bytes, (hipStream_t)stream), "stream_probe");
+}
+
 #ifdef P2V_DIAG
 /* diagnostic build only (make diag): device buffer receiving 6 x uint64 per workgroup of the next tiled GEMM launches */
 extern unsigned long long* g_gemm_stamps;

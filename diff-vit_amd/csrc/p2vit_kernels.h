@@ -82,6 +82,7 @@ inline int p2v_resident_tokens_of(int head_dim) {
   if (head_dim == 32 || head_dim == 48 || head_dim == 64 || head_dim == 80) return P2V_MAX_TOKENS;
   return head_dim == 96 ? 17 * 32 : (head_dim == 128 ? 12 * 32 : 0);
 }
+int p2v_launch_stream_probe(int kernels, int usec, int workgroups, int lds_bytes, hipStream_t st);     // trains of one-wave timed waits (p2vit_misc.hip)
 int p2v_launch_fake_quant(const float* x, long long n, const float* scale, int n_scale, long long inner, int lo, int hi,
                           float* out, int8_t* codes, hipStream_t st);
 int p2v_launch_gelu_quant(const float* y, long long n, float inv_s, int8_t* codes, unsigned long long* flags, int force_slow,

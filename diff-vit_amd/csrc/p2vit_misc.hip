@@ -258,3 +258,25 @@ int p2v_launch_gelu_table_check(float inv_s, const p2v_gelu_tab& t, unsigned lon
   return 0;
 }
 
+// ---- stream probe: `kernels` launches of one wave that waits `usec` microseconds on the constant-rate counter ------------------------------
+// No memory traffic, one wave: two streams whose hardware queues are serviced concurrently finish a train of these in the time of one train;
+// queues that share a dispatch pipe (or streams that share a queue) take the sum.  The host side (engine.side_streams) uses it to pick side
+// streams for the batch slicing that really run beside the caller's stream.  Every wave leaves the loop: the counter advances on its own.
+__global__ __launch_bounds__(256) void k_stream_probe(long long ticks) {
+  extern __shared__ unsigned char probe_lds[];
+  if (ticks < 0) probe_lds[threadIdx.x] = 0;                  // (keeps the dynamic LDS allocation)
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+int p2v_launch_stream_probe(int kernels, int usec, int workgroups, int lds_bytes, hipStream_t st) {
+  int dev = 0, khz = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
+  if (e != hipSuccess) return (int)e;
+  if (khz <= 0) khz = 100000;
+  const long long ticks = (long long)usec * khz / 1000;
+  for (int i = 0; i < kernels; ++i) hipLaunchKernelGGL(k_stream_probe, dim3(workgroups), dim3(256), lds_bytes, st, ticks);
+  CHECK_LAUNCH();
+  return 0;
+}

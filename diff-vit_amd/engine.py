@@ -139,6 +139,7 @@ def lib():
     L.p2v_fake_quant_f32.argtypes = [_p, _ll, _p, _i, _ll, _i, _i, _p, _p, _p]
     L.p2v_gelu_quant_f32.argtypes = [_p, _ll, _f, _p, _p, _i, _p]
     L.p2v_gelu_err_sweep.argtypes = [C.c_uint32, C.c_uint32, _p, _p]
+    L.p2v_stream_probe.argtypes = [_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.p2v_gelu_table_plan.argtypes = [_f, C.POINTER(GeluTab)]
     L.p2v_gelu_table_scratch_bytes.argtypes = [_i]
     L.p2v_gelu_table_scratch_bytes.restype = C.c_size_t
@@ -237,3 +238,72 @@ def pack_int4_tiles(wp):
 def ptr(t):
     """device pointer of a torch tensor (or None)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ---- side HIP streams of the batch slicing: ONE probed set per device for the whole process ------------------------------------------
+# A HIP stream gets a hardware queue when it first carries work, in order (GPU_MAX_HW_QUEUES of them, then round again), and the queues are
+# served by FOUR dispatch pipes: queue i and queue i + 4 share one.  Two streams with work in them at the same time on one pipe do not just
+# serialise - every kernel waits for a queue switch, and the sliced forward falls BELOW the one-stream rate (profiles/r04_stream_pool.txt:
+# DeiT-S 101 k img/s -> 57 - 68 k as soon as the process had used one to three other streams before the plan took its own; 82 k on one stream).
+# So (a) plans do not own streams, they borrow this one set, and (b) the set is PROBED: candidates are kept only if a train of timed
+# one-wave kernels (p2v_stream_probe) on them runs beside the same train on the caller's stream and on the streams already kept.
+_SIDE_STREAMS = {}
+SIDE_STREAM_REPORT = {}          # per device index: what the probe saw (bench.py prints it)
+MAX_SIDE_STREAMS = 3
+
+
+def _pair_ms(a, b, kernels=10, usec=20, wgs=64, lds=0):
+    """wall time (ms) of a train of timed kernels on stream ``a`` and the same train on ``b``, enqueued together; best of two tries"""
+    import time
+    import torch
+    L = lib()
+    best = 1e9
+    for _ in range(2):
+        a.synchronize(); b.synchronize()
+        t0 = time.perf_counter()
+        check(L.p2v_stream_probe(C.c_void_p(a.cuda_stream), kernels, usec, wgs, lds))
+        check(L.p2v_stream_probe(C.c_void_p(b.cuda_stream), kernels, usec, wgs, lds))
+        a.synchronize(); b.synchronize()
+        best = min(best, (time.perf_counter() - t0) * 1e3)
+    return best
+
+
+def side_streams(device, n):
+    """the first ``n`` shared side streams of ``device`` (useful: up to MAX_SIDE_STREAMS); chosen once, on first use, among up to twelve
+    candidates, by the probe above against the stream that is current at that moment (the caller's) and against each other."""
+    import torch
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    pool = _SIDE_STREAMS.get(idx)
+    if pool is None:
+        with torch.cuda.device(idx):
+            cur = torch.cuda.current_stream(idx)
+            kernels, usec, wgs = 10, 20, 64
+            alone = kernels * usec * 1e-3                       # one train: 0.2 ms; measured: 0.26 - 0.27 ms for two trains side by side,
+            limit = 2.0 * alone                                 # 0.55 - 0.60 ms when the two queues share a pipe or the streams a queue
+            pool, tried, rejected = [], 0, []
+            while len(pool) < MAX_SIDE_STREAMS and tried < 12:
+                st = torch.cuda.Stream(device=idx)
+                tried += 1
+                worst = max(_pair_ms(st, o, kernels, usec, wgs) for o in [cur] + pool)
+                if worst <= limit:
+                    pool.append(st)
+                else:
+                    rejected.append(round(worst, 3))
+            probed = len(pool)
+            while len(pool) < MAX_SIDE_STREAMS:                 # nothing better found: plain streams (and say so)
+                pool.append(torch.cuda.Stream(device=idx))
+            SIDE_STREAM_REPORT[idx] = {'candidates': tried, 'kept_by_probe': probed, 'rejected_pair_ms': rejected, 'limit_ms': round(limit, 3)}
+            if probed < MAX_SIDE_STREAMS:
+                import warnings
+                warnings.warn('diff_vit_amd: only %d of %d side streams run beside the caller\'s stream on device %d (other streams of the '
+                              'process hold the hardware queues): the sliced forward may run below the one-stream rate; pass n_streams=1'
+                              % (probed, MAX_SIDE_STREAMS, idx), RuntimeWarning, stacklevel=3)
+        _SIDE_STREAMS[idx] = pool
+    if n > MAX_SIDE_STREAMS:
+        import warnings
+        warnings.warn('%d side streams: with the caller\'s stream more than four streams carry work, and the step collapses to about half its '
+                      'speed (profiles/r04_slices.txt); %d is the useful maximum' % (n, MAX_SIDE_STREAMS), RuntimeWarning, stacklevel=3)
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=idx))
+    return pool[:n]

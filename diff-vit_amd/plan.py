@@ -279,6 +279,11 @@ class FrozenPlan:
         cfg = (C.c_int8 * len(bit_config))(*[int(b) if -128 <= int(b) <= 127 else 127 for b in bit_config])
         return images.contiguous().float(), cfg
 
+    def _check_out(self, out, B):
+        # the C ABI writes B x classes floats through the raw pointer
+        if tuple(out.shape) != (B, self.arch['num_classes']) or out.device != self.device or out.dtype != torch.float32 or not out.is_contiguous():
+            raise AssertionError('out must be a contiguous fp32 [%d, %d] tensor on %s' % (B, self.arch['num_classes'], self.device))
+
     def forward(self, images, bit_config, stop_after=-1, out=None, taps=None):
         """images: fp32 [B,C,H,W] on the plan's device -> fp32 logits [B, classes] (int8 grid * act_out scale).
         ``taps`` (dict): filled with 'qkv_output' / 'fc1_output' -> list of fp32 [B, tokens, 3D] / [B, tokens, hidden] tensors per
@@ -290,6 +295,8 @@ class FrozenPlan:
             ws = self.workspace(B)
             if out is None:
                 out = torch.empty(B, self.arch['num_classes'], dtype=torch.float32, device=self.device)
+            else:
+                self._check_out(out, B)
             if taps is None:
                 E.check(E.lib().p2v_forward(self._handle, E.ptr(images), B, cfg, len(bit_config), E.ptr(out), E.ptr(ws),
                                             ws.numel(), stop_after, E.stream_ptr(self.device)))
@@ -304,21 +311,29 @@ class FrozenPlan:
         return out
 
     def slice_sizes(self, batch, n_streams=3):
-        """Batch slices of ``forward_streams``: ``n_streams`` slices for the side streams plus ONE more, smaller, for the caller's own stream
-        (256 -> 68 + 68 + 68 + 52).  Four kernels in flight on four hardware queues is what the runtime sustains - a fourth SIDE stream (five
-        streams with the caller's) collapses to 57 k img/s - and the fourth slice is worth +1.7 % over three (86 + 85 + 85) in the same call, with
-        or without an initialised RCCL group (round 4, profiles/r04_slices.txt; 64 x 4, 60 + 60 + 60 + 76 and 70 + 62 + 62 + 62 lie within
-        0.5 % of each other).  Round 3 (profiles/r03_slicing.txt): any split into THREE gives the same step time within 1 %."""
-        if n_streams <= 1 or batch < 2 * n_streams:
+        """Batch slices of ``forward_streams`` for up to ``n_streams`` side streams plus the caller's own stream (256 -> 68 + 68 + 68 + 52).
+        Four kernels in flight on four hardware queues is what the device sustains - a fourth SIDE stream (five streams with the caller's)
+        collapses to 57 k img/s, see ``engine.side_streams`` - and the caller's stream carries ~0.77 of a side slice.
+
+        How many slices pays depends on the work per slice (profiles/r04_sweep_slices.txt, same-call sweeps over widths 192 / 384 / 768,
+        197 / 577 tokens and batches of 16 ... 512): for the models whose blocks run the fused LayerNorm+GEMM kernels (widths up to 384) one
+        slice per ~8 k rows (batch x tokens) at width 384 - proportionally more rows for narrower models - and at least 32 images per slice
+        (the attention launch has images x heads workgroups): DeiT-S 32 images -> one slice, 64 -> two (+4 %), 128 -> three (+15 %),
+        192 and more -> four (+20 %); 64 images at 577 tokens -> two (+29 %).  The MFMA-bound wide models gain from exactly TWO balanced slices
+        on side streams (ViT-B b512 36.1 k img/s against 35.2 k on one stream and 35.8 k on three; DeiT-B W4 40.1 / 38.2 / 39.1 k)."""
+        if n_streams <= 1 or batch < 2:
             return [batch]
-        # ... for the models whose blocks run the fused LayerNorm+GEMM kernels (widths up to 384).  The MFMA-bound wide models lose with a third /
-        # fourth slice: ViT-B b512 35.5 k img/s at 256 + 256 against 34.8 k at 186 + 186 + 140, DeiT-B W4 39.3 k at 128 + 128 against 38.3 k
-        if batch < 16 * (n_streams + 1) or self.D > 384:       # (and small batches): a balanced split over the side streams only
-            q, r = divmod(batch, n_streams)
-            return [q + (1 if i < r else 0) for i in range(n_streams)]
-        d = 1000 * n_streams + 765                     # the caller's slice is ~0.77 of a side slice (52 : 68)
+        if self.D > 384:
+            if batch < 64:
+                return [batch]
+            return [(batch + 1) // 2, batch // 2]
+        target = 8192 * 384 // self.D                                   # rows (batch x tokens) per slice
+        k = min((2 * batch * self.tokens + target) // (2 * target), batch // 32, n_streams + 1)
+        if k <= 1:
+            return [batch]
+        d = 1000 * (k - 1) + 765                                        # the caller's slice is ~0.77 of a side slice (52 : 68)
         side = (batch * 1000 + d - 1) // d
-        return [side] * n_streams + [batch - n_streams * side]
+        return [side] * (k - 1) + [batch - (k - 1) * side]
 
     def forward_streams(self, images, bit_config, out, n_streams=3, slices=None):
         """Same result as ``forward``; the batch is cut into contiguous slices (``slice_sizes`` or an explicit list) that run on
@@ -330,14 +345,12 @@ class FrozenPlan:
         sizes = list(slices) if slices is not None else self.slice_sizes(B, n_streams)
         if sum(sizes) != B or min(sizes) < 1:
             raise AssertionError('slices %r do not cover a batch of %d' % (sizes, B))
+        self._check_out(out, B)
         if len(sizes) == 1:
             return self.forward(images, bit_config, out=out)
-        if tuple(out.shape) != (B, self.arch['num_classes']) or out.device != self.device or out.dtype != torch.float32 or not out.is_contiguous():
-            raise AssertionError('out must be a contiguous fp32 [%d, %d] tensor on %s' % (B, self.arch['num_classes'], self.device))
         with torch.cuda.device(self.device):
             n_side = min(len(sizes), max(n_streams, 1))
-            if getattr(self, '_streams', None) is None or len(self._streams) < n_side:
-                self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_side)]
+            self._streams = E.side_streams(self.device, n_side)         # the process's shared side streams of this device, never new ones
             if getattr(self, '_ws_multi', None) is None or len(self._ws_multi) < len(sizes):
                 self._ws_multi = (getattr(self, '_ws_multi', None) or []) + [None] * (len(sizes) - len(getattr(self, '_ws_multi', None) or []))
             cur = torch.cuda.current_stream(self.device)

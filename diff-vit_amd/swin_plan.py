@@ -386,8 +386,7 @@ class SwinPlan:
             slices = [min(step, B - i * step) for i in range(n_streams) if i * step < B]
         if sum(slices) != B or min(slices) < 1:
             raise AssertionError('slices %r do not cover a batch of %d' % (list(slices), B))
-        if getattr(self, '_streams', None) is None or len(self._streams) != n_streams:
-            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+        self._streams = E.side_streams(self.device, n_streams)          # the process's shared side streams of this device (engine.side_streams)
         cur = torch.cuda.current_stream(self.device)
         outs, lo = [], 0
         for i, n_i in enumerate(slices):
