@@ -253,12 +253,12 @@ MAX_SIDE_STREAMS = 3
 
 
 def _pair_ms(a, b, kernels=10, usec=20, wgs=64, lds=0):
-    """wall time (ms) of a train of timed kernels on stream ``a`` and the same train on ``b``, enqueued together; best of two tries"""
+    """wall time (ms) of a train of timed kernels on stream ``a`` and the same train on ``b``, enqueued together; best of three tries (host wall clock)"""
     import time
     import torch
     L = lib()
     best = 1e9
-    for _ in range(2):
+    for _ in range(3):
         a.synchronize(); b.synchronize()
         t0 = time.perf_counter()
         check(L.p2v_stream_probe(C.c_void_p(a.cuda_stream), kernels, usec, wgs, lds))
