@@ -84,10 +84,10 @@ def build_loaders(data_root, model_name, val_batchsize, calib_batchsize, num_wor
     mean, std, crop_pct = MODEL_STATS[family]
     tf = build_transform(mean=mean, std=std, crop_pct=crop_pct)
     val = torch.utils.data.DataLoader(ImageFolder(os.path.join(data_root, 'val'), tf), batch_size=val_batchsize, shuffle=False,
-                                      num_workers=num_workers, pin_memory=False)
+                                      num_workers=num_workers, pin_memory=torch.cuda.is_available())       # (test_quant.py:128: pin_memory=True)
     train_dir = os.path.join(data_root, 'train')
     train = None
     if os.path.isdir(train_dir):
         train = torch.utils.data.DataLoader(ImageFolder(train_dir, tf), batch_size=calib_batchsize, shuffle=True, num_workers=num_workers,
-                                            pin_memory=False, drop_last=True)
+                                            pin_memory=torch.cuda.is_available(), drop_last=True)
     return val, train

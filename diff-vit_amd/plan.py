@@ -342,6 +342,7 @@ class FrozenPlan:
         or MFMA-bound phases of another slice's kernels."""
         images, cfg = self._check(images, bit_config)
         B = images.shape[0]
+        n_streams = min(n_streams, E.compute_side_streams(self.device))      # (one less while an input pipeline copies on engine.copy_stream)
         sizes = list(slices) if slices is not None else self.slice_sizes(B, n_streams)
         if sum(sizes) != B or min(sizes) < 1:
             raise AssertionError('slices %r do not cover a batch of %d' % (sizes, B))
@@ -398,6 +399,7 @@ class FrozenPlan:
         A batch that runs as ONE slice has no overlap: the isolated profile is returned."""
         images, cfg = self._check(images, bit_config)
         B = images.shape[0]
+        n_streams = min(n_streams, E.compute_side_streams(self.device))
         sizes = list(slices) if slices is not None else self.slice_sizes(B, n_streams)
         if len(sizes) == 1:
             per = self.profile(images, bit_config)

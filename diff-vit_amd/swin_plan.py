@@ -379,6 +379,7 @@ class SwinPlan:
         ``slices``: explicit slice sizes; slices beyond ``n_streams`` run on the caller's stream."""
         images = self._check_images(images)
         B = images.shape[0]
+        n_streams = min(n_streams, E.compute_side_streams(self.device))       # (one less while an input pipeline copies on engine.copy_stream)
         if taps is not None or n_streams <= 1 or (slices is None and B < 16 * n_streams):
             return self._replay(images, 0, taps)
         if slices is None:

@@ -103,3 +103,13 @@ def test_pretrained_true_reads_the_torch_hub_cache(tmp_path, monkeypatch):
                                         'swin_small_patch4_window7_224', 'swin_base_patch4_window7_224'}
     with pytest.raises(FileNotFoundError):
         dva.swin_tiny_patch4_window7_224(pretrained=True)
+
+
+def test_device_prefetcher_on_cpu_is_a_pass_through():
+    """harness.DevicePrefetcher on a CPU device: the loader's batches, in order (the copy stream exists on a GPU only)."""
+    import diff_vit_amd as dva
+    batches = [(torch.full((2, 3), float(i)), torch.tensor([i, i + 1])) for i in range(3)]
+    out = list(dva.harness.DevicePrefetcher(batches, 'cpu'))
+    assert len(out) == 3 and len(dva.harness.DevicePrefetcher(batches, 'cpu')) == 3
+    for (x, t), (gx, gt) in zip(batches, out):
+        assert torch.equal(x, gx) and torch.equal(t, gt) and gx.device.type == 'cpu'

@@ -1270,6 +1270,31 @@ def test_swin_batch_independence_and_stream_slices(dva):
         m._plan.forward(x)                                   # CPU tensor: no fallback
 
 
+def test_device_prefetcher_hands_over_the_batches_in_order(dva, micro):
+    """harness.DevicePrefetcher: batch i + 1 is copied on engine.copy_stream while batch i runs; every batch arrives complete and in order
+    (pinned and pageable host tensors), the logits equal the copy-then-forward loop, and the sliced forward keeps off the copy stream."""
+    E = dva.engine
+    plan = dva.FrozenPlan(micro['arch'], micro['sd'], micro['calib'])
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.randn(6, 3, 32, 32, generator=g), torch.arange(6) + 10 * i) for i in range(5)]
+    batches = [(x.pin_memory() if i % 2 == 0 else x, t) for i, (x, t) in enumerate(batches)]
+    bc = [8] * 10
+    try:
+        got = []
+        for x, t in dva.harness.DevicePrefetcher(batches, 'cuda'):
+            assert x.is_cuda and t.is_cuda
+            got.append((x.clone(), t.clone(), plan.forward(x, bc).clone()))
+        assert len(got) == 5 and len(dva.harness.DevicePrefetcher(batches, 'cuda')) == 5
+        assert E.compute_side_streams('cuda') == E.MAX_SIDE_STREAMS - 1
+        assert E.copy_stream('cuda') is E.side_streams('cuda', 3)[2]
+        for (x, t), (gx, gt, lg) in zip(batches, got):
+            assert torch.equal(gx.cpu(), x) and torch.equal(gt.cpu(), t)
+            assert torch.equal(lg, plan.forward(x.cuda(), bc))
+    finally:
+        E._COPY_STREAM.clear()                                        # the rest of this process slices over three side streams again
+    assert E.compute_side_streams('cuda') == E.MAX_SIDE_STREAMS
+
+
 def test_side_streams_are_probed_against_shared_dispatch_pipes():
     """engine.side_streams: when other streams of the process carried work first, the next streams torch hands out land on hardware
     queues that share a dispatch pipe with the caller's, and the sliced forward runs BELOW the one-stream rate (profiles/r04_stream_pool.txt:
