@@ -431,10 +431,11 @@ int p2v_gelu_quant_f32(const float* y, long long n, float inv_s, int8_t* codes, 
  * (dev, fp32 bits compared as unsigned) must be zeroed by the caller.  Bound check for the epilogue. */
 int p2v_gelu_err_sweep(unsigned first_bits, unsigned count, float* max_err, void* stream);
 
-/* Scheduling aid, no data: enqueues `kernels` (1..64) launches of ONE wave that waits `usec` (1..1000) microseconds on the device's
- * constant-rate counter.  Two streams whose hardware queues are serviced concurrently finish two such trains in the time of one; streams
- * whose queues share a dispatch pipe take the sum - and a sliced forward on such a pair runs at HALF speed (profiles/r04_stream_pool.txt).
- * The host side probes candidate side streams with it before the first sliced forward (engine.side_streams). */
+/* Scheduling aid, no data: enqueues `kernels` (1..64) launches of `workgroups` (1..4096) workgroups of 256 threads (with `lds_bytes`, 0..65536,
+ * of LDS each) that wait `usec` (1..1000) microseconds on the device's constant-rate counter.  Two streams whose hardware queues are served
+ * concurrently finish two such trains in little more than the time of one (10 x 20 us, 64 workgroups: 0.26 ms); streams whose queues share
+ * a dispatch pipe, or that share a queue, take 0.46 - 0.60 ms - and a sliced forward on such a pair runs BELOW the one-stream rate
+ * (profiles/r04_stream_pool.txt).  The host side probes candidate side streams with it before the first sliced forward (engine.side_streams). */
 int p2v_stream_probe(void* stream, int kernels, int usec, int workgroups, int lds_bytes);
 
 const char* p2v_last_error(void);
