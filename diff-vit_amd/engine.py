@@ -275,6 +275,9 @@ def side_streams(device, n):
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     pool = _SIDE_STREAMS.get(idx)
+    if pool is None and torch.cuda.is_current_stream_capturing():
+        # a first call inside a graph capture cannot synchronise, i.e. cannot probe: plain streams for this capture, the pool stays unchosen
+        return [torch.cuda.Stream(device=idx) for _ in range(n)]
     if pool is None:
         with torch.cuda.device(idx):
             cur = torch.cuda.current_stream(idx)
