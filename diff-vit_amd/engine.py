@@ -312,26 +312,34 @@ def side_streams(device, n):
     return pool[:n]
 
 
-_COPY_STREAM = {}
+_COPY_STREAM = {}          # device index -> number of input pipelines currently copying on the pool's third side stream
+
+
+def _dev_index(device):
+    import torch
+    dev = torch.device(device)
+    return dev.index if dev.index is not None else torch.cuda.current_device()
 
 
 def copy_stream(device):
     """the stream for the host -> device copies of an input pipeline that prefetches the next batch while this one runs
-    (``harness.DevicePrefetcher``): the pool's THIRD side stream, i.e. one that was probed to have a dispatch pipe of its own.  From this call
-    on the sliced forward of the device keeps to two side streams + the caller's (three slices in flight): a fifth busy stream has to share a
-    pipe with a slice, and the double-buffered DeiT-S loop then runs at 50 k img/s instead of 82 k (copy bound at 53 - 56 GB/s: 88 - 93 k;
-    profiles/r04_pcie.txt)."""
-    import torch
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    (``harness.DevicePrefetcher``): the pool's THIRD side stream, i.e. one that was probed to have a dispatch pipe of its own.  Until the
+    matching ``release_copy_stream`` the sliced forward of the device keeps to two side streams + the caller's (three slices in flight): a
+    fifth busy stream has to share a pipe with a slice, and the double-buffered DeiT-S loop then runs at 50 k img/s instead of 84 k (copy
+    bound at 53 - 57 GB/s: 88 - 95 k; profiles/r04_pcie.txt)."""
+    idx = _dev_index(device)
     st = side_streams(idx, MAX_SIDE_STREAMS)[MAX_SIDE_STREAMS - 1]
-    _COPY_STREAM[idx] = st
+    _COPY_STREAM[idx] = _COPY_STREAM.get(idx, 0) + 1
     return st
 
 
+def release_copy_stream(device):
+    """the input pipeline is done: the sliced forward may use all side streams again"""
+    idx = _dev_index(device)
+    if _COPY_STREAM.get(idx, 0) > 0:
+        _COPY_STREAM[idx] -= 1
+
+
 def compute_side_streams(device):
-    """side streams the sliced forward may use on ``device``: MAX_SIDE_STREAMS, one less once ``copy_stream`` was handed out"""
-    import torch
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    return MAX_SIDE_STREAMS - (1 if idx in _COPY_STREAM else 0)
+    """side streams the sliced forward may use on ``device``: MAX_SIDE_STREAMS, one less while a ``copy_stream`` is handed out"""
+    return MAX_SIDE_STREAMS - (1 if _COPY_STREAM.get(_dev_index(device), 0) > 0 else 0)

@@ -197,19 +197,22 @@ class DevicePrefetcher:
             return
         from . import engine as E
         st = E.copy_stream(dev)
-        ahead = None
-        for data, target in self.loader:
-            cur = torch.cuda.current_stream(dev)
-            st.wait_stream(cur)                       # (the caching allocator may hand the copy a block the current stream just released)
-            with torch.cuda.stream(st):
-                d, t = data.to(dev, non_blocking=True), target.to(dev, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(st)
+        try:
+            ahead = None
+            for data, target in self.loader:
+                cur = torch.cuda.current_stream(dev)
+                st.wait_stream(cur)                       # (the caching allocator may hand the copy a block the current stream just released)
+                with torch.cuda.stream(st):
+                    d, t = data.to(dev, non_blocking=True), target.to(dev, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                if ahead is not None:
+                    yield self._hand_over(ahead, dev)
+                ahead = (d, t, ev)
             if ahead is not None:
                 yield self._hand_over(ahead, dev)
-            ahead = (d, t, ev)
-        if ahead is not None:
-            yield self._hand_over(ahead, dev)
+        finally:
+            E.release_copy_stream(dev)                    # (also when the consumer stops early): all side streams serve the forward again
 
     @staticmethod
     def _hand_over(item, dev):

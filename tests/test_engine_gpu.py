@@ -1279,20 +1279,24 @@ def test_device_prefetcher_hands_over_the_batches_in_order(dva, micro):
     batches = [(torch.randn(6, 3, 32, 32, generator=g), torch.arange(6) + 10 * i) for i in range(5)]
     batches = [(x.pin_memory() if i % 2 == 0 else x, t) for i, (x, t) in enumerate(batches)]
     bc = [8] * 10
-    try:
-        got = []
-        for x, t in dva.harness.DevicePrefetcher(batches, 'cuda'):
-            assert x.is_cuda and t.is_cuda
-            got.append((x.clone(), t.clone(), plan.forward(x, bc).clone()))
-        assert len(got) == 5 and len(dva.harness.DevicePrefetcher(batches, 'cuda')) == 5
-        assert E.compute_side_streams('cuda') == E.MAX_SIDE_STREAMS - 1
-        assert E.copy_stream('cuda') is E.side_streams('cuda', 3)[2]
-        for (x, t), (gx, gt, lg) in zip(batches, got):
-            assert torch.equal(gx.cpu(), x) and torch.equal(gt.cpu(), t)
-            assert torch.equal(lg, plan.forward(x.cuda(), bc))
-    finally:
-        E._COPY_STREAM.clear()                                        # the rest of this process slices over three side streams again
+    got = []
+    for x, t in dva.harness.DevicePrefetcher(batches, 'cuda'):
+        assert x.is_cuda and t.is_cuda
+        assert E.compute_side_streams('cuda') == E.MAX_SIDE_STREAMS - 1      # while the pipeline copies, the forward leaves its stream alone
+        got.append((x.clone(), t.clone(), plan.forward(x, bc).clone()))
+    assert len(got) == 5 and len(dva.harness.DevicePrefetcher(batches, 'cuda')) == 5
+    assert E.compute_side_streams('cuda') == E.MAX_SIDE_STREAMS              # ... and gets it back when the loader is exhausted
+    for (x, t), (gx, gt, lg) in zip(batches, got):
+        assert torch.equal(gx.cpu(), x) and torch.equal(gt.cpu(), t)
+        assert torch.equal(lg, plan.forward(x.cuda(), bc))
+    it = iter(dva.harness.DevicePrefetcher(batches, 'cuda'))                  # a consumer that stops early releases it as well
+    next(it)
+    assert E.compute_side_streams('cuda') == E.MAX_SIDE_STREAMS - 1
+    it.close()
     assert E.compute_side_streams('cuda') == E.MAX_SIDE_STREAMS
+    st = E.copy_stream('cuda')
+    assert st is E.side_streams('cuda', 3)[2]
+    E.release_copy_stream('cuda')
 
 
 def test_side_streams_are_probed_against_shared_dispatch_pipes():
