@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by RUNNING THE REAL REFERENCE (imported from /root/reference) on CPU.
 
-Run once in the build container:   python oracle/gen_golden.py [micro|deit_small|deit_small_margin|deit_tiny_fp|kat|all]
+Run once in the build container:   python oracle/gen_golden.py [micro|deit_small|deit_small_margin|vit_base|deit_tiny|deit_tiny_fp|kat|all]
 
 Nothing of the reference is copied: only its inputs and outputs (data) are stored.  The reference
 hard-codes ``.cuda()`` in its forward (e.g. models/vit_fquant.py:206, quantizer/uniform.py:85), which
@@ -314,6 +314,12 @@ def main():
     if what in ('deit_small', 'all'):
         keep = lambda n: n.startswith(('blocks.0.', 'blocks.11.')) or '.' not in n or n.startswith('patch_embed')
         gen_model_fixture('deit_small', synth.ARCHS['deit_small'], 3, 2, 4, False, keep, ref)
+    if what in ('deit_tiny', 'all'):
+        # the architecture of BASELINE config 1 (192 wide, 3 heads) on the QUANTIZED path: logits and the top-level taps
+        gen_model_fixture('deit_tiny', synth.ARCHS['deit_tiny'], 17, 2, 2, False, lambda n: '.' not in n, ref)
+    if what in ('vit_base', 'all'):
+        # BASELINE configs 3 / 5 (ViT-B and DeiT-B share the architecture: 768 wide, 12 heads, fc2 with K = 3072): logits and the top-level taps
+        gen_model_fixture('vit_base', synth.ARCHS['vit_base'], 13, 2, 2, False, lambda n: '.' not in n, ref)
     if what in ('deit_small_margin', 'all'):
         # same architecture, seed 5, 8 evaluation images, a head with planted classes (plant_head_margin): top-1 testable at 4 bits
         gen_model_fixture('deit_small_margin', synth.ARCHS['deit_small'], 5, 2, 8, False, lambda n: '.' not in n, ref, sd_hook=plant_head_margin)

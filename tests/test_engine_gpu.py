@@ -163,6 +163,34 @@ def test_deit_small_vs_oracle_and_golden(dva, oracle, synth):
             assert np.array_equal(got, taps[name].reshape(B * T, cols).numpy().astype(np.int64)), (tag, name)
 
 
+@pytest.mark.parametrize('name', ['vit_base', 'deit_tiny'])
+def test_other_architectures_vs_oracle_and_golden(dva, oracle, synth, name):
+    """BASELINE configs 3 / 5 (ViT-B = DeiT-B architecture) and the DeiT-T architecture of config 1 on the engine with the REAL reference's
+    calibration state (tests/golden/vit_base.npz, deit_tiny.npz): logits bit-equal to the canonical oracle for [8]*50, [4]*50 (packed int4
+    weights) and the mixed list, and as far from the reference's logits as the fixture records for the canonical reading
+    (test_oracle_golden.py::test_other_architectures_are_the_reference closes the chain oracle == reference).  At DeiT-T the engine's
+    logits EQUAL THE REAL REFERENCE'S for [8]*50 and [4]*50 - no platform-dependent rounding happens to flip a code there."""
+    g = load_golden(name)
+    arch = synth.ARCHS[name]
+    seed = int(g['seed'])
+    sd = synth.vit_state_dict(arch, seed)
+    calib = golden_calib(g, oracle)
+    plan = dva.FrozenPlan(arch, sd, calib)
+    x = synth.images(seed, int(g['n_eval']), 224, offset=1000)
+    orc = oracle.OracleViT(arch, sd)
+    orc.calib = calib
+    s_o = float(g['calib/act_out'].reshape(-1)[0])
+    for tag in ('q8', 'q4', 'qmix'):
+        bits = _bits(g, tag, 50)
+        out = plan.forward(x.cuda(), bits).cpu()
+        assert np.array_equal(out.numpy(), orc.quant_forward(x, bits).numpy()), tag
+        d = np.abs(np.round((out.numpy() - g['logits/' + tag]) / s_o))
+        assert int((d > 0).sum()) == int(g['canon_vs_ref/%s/logit_codes_differ' % tag]), tag
+        assert int((out.argmax(1).numpy() == g['logits/' + tag].argmax(1)).sum()) == int(g['canon_vs_ref/%s/top1_agree' % tag]), tag
+        if name == 'deit_tiny' and tag != 'qmix':
+            assert np.array_equal(out.numpy(), g['logits/' + tag]), tag             # HIP engine == REAL reference, every logit
+
+
 def test_deit_small_margin_top1_identical_on_gpu(dva, oracle, synth):
     """the HIP engine on the planted-margin DeiT-S fixture (tests/golden/deit_small_margin.npz): logits bit-equal to the canonical
     oracle, and top-1 IDENTICAL to the real reference's on all 8 images for [8]*50, [4]*50 and the mixed list."""

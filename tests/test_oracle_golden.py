@@ -143,6 +143,36 @@ def test_deit_small_decomposition(oracle, synth):
     assert run(drop('lis'), 'q4')[0] > 0 and run(drop('ln'), 'q4')[0] > 0
 
 
+@pytest.mark.parametrize('name', ['vit_base', 'deit_tiny'])
+def test_other_architectures_are_the_reference(oracle, synth, name):
+    """BASELINE configs 3 / 5 (ViT-B and DeiT-B share the architecture: 768 wide, 12 heads, fc2 with a 3072-deep contraction) and the
+    architecture of config 1 (DeiT-T: 192 wide, 3 heads) on the quantized path against the REAL reference (tests/golden/vit_base.npz,
+    deit_tiny.npz: its calibration state, logits and top-level taps for [8]*50, [4]*50 and the mixed list).  With the four torch-CPU pieces
+    switched back in the oracle IS the reference at these sizes too - 0 logit codes differ; the canonical oracle (what the HIP engine
+    computes) agrees up to the platform-dependent roundings, counted in the fixture - at DeiT-T that count is ZERO for [8]*50 and [4]*50."""
+    g = load_golden(name)
+    arch = synth.ARCHS[name]
+    sd = synth.vit_state_dict(arch, int(g['seed']))
+    calib = golden_calib(g, oracle)
+    x = synth.images(int(g['seed']), int(g['n_eval']), 224, offset=1000)
+    s_o = float(g['calib/act_out'].reshape(-1)[0])
+    cfgs = {'q8': [8] * 50, 'q4': [4] * 50, 'qmix': [int(b) for b in g['bit_qmix']]}
+    ref_like = oracle.OracleViT(arch, sd, imitate=oracle.OracleViT.IMITATE)
+    ref_like.calib = calib
+    for tag, bits in cfgs.items():
+        out = ref_like.quant_forward(x, bits)
+        assert int((np.round((out.numpy() - g['logits/' + tag]) / s_o) != 0).sum()) == 0, tag
+    orc = oracle.OracleViT(arch, sd)
+    orc.calib = calib
+    for tag in (('q8', 'q4') if name == 'deit_tiny' else ('q8',)):
+        out = orc.quant_forward(x, cfgs[tag])
+        d = np.abs(np.round((out.numpy() - g['logits/' + tag]) / s_o))
+        assert int((d > 0).sum()) == int(g['canon_vs_ref/%s/logit_codes_differ' % tag])
+        assert int((out.argmax(1).numpy() == g['logits/' + tag].argmax(1)).sum()) == int(g['canon_vs_ref/%s/top1_agree' % tag])
+        if name == 'deit_tiny':
+            assert np.array_equal(out.numpy(), g['logits/' + tag]), tag          # canonical oracle == REAL reference, every logit
+
+
 def test_deit_small_margin_top1_identical(oracle, synth):
     """north_star's 'identical top-1 indices' at DeiT-S size, made testable: the head of this fixture carries one planted class per
     evaluation image (oracle/gen_golden.py::plant_head_margin), so every top-1 leads the runner-up by > 80 codes while the
