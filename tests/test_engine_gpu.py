@@ -633,7 +633,9 @@ def test_lis_attention(dva, oracle, B, N, H, hd, e_at):
 
 
 @pytest.mark.parametrize('B,N,H,hd,e_at', [(1, 609, 2, 64, 4), (1, 785, 1, 64, 5), (1, 1025, 1, 64, 4), (2, 577, 1, 128, 4), (1, 600, 1, 96, 5),
-                                          (1, 700, 2, 32, 4), (1, 650, 1, 80, 4), (1, 620, 1, 48, 4)])
+                                          (1, 700, 2, 32, 4), (1, 650, 1, 80, 4), (1, 620, 1, 48, 4),
+                                          # the largest the plan accepts (P2V_MAX_TOKENS_STREAMED: 64 KB of packed codes per wave) and one short of it, widest head
+                                          (1, 4096, 1, 64, 4), (1, 4095, 1, 128, 5)])
 def test_lis_attention_streamed(dva, oracle, B, N, H, hd, e_at):
     """token counts beyond what the resident kernel holds in LDS (608; 544 / 384 at head_dim 96 / 128) run the streaming kernel (round 4:
     448^2 / 16 = 785, 512^2 / 16 = 1025 tokens ...): every softmax exponent and every output code against the oracle."""
