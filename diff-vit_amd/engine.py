@@ -246,8 +246,10 @@ def ptr(t):
 # serialise - every kernel waits for a queue switch, and the sliced forward falls BELOW the one-stream rate (profiles/r04_stream_pool.txt:
 # DeiT-S 101 k img/s -> 57 - 68 k as soon as the process had used one to three other streams before the plan took its own; 82 k on one stream).
 # So (a) plans do not own streams, they borrow this one set, and (b) the set is PROBED: candidates are kept only if a train of timed
-# one-wave kernels (p2v_stream_probe) on them runs beside the same train on the caller's stream and on the streams already kept.
+# kernels (p2v_stream_probe: 64 workgroups that wait 20 us) on them runs beside the same train on the caller's stream and on the streams already kept.
+import threading as _threading
 _SIDE_STREAMS = {}
+_SIDE_LOCK = _threading.Lock()   # the pool is chosen once per device, whichever host thread asks first
 SIDE_STREAM_REPORT = {}          # per device index: what the probe saw (bench.py prints it)
 MAX_SIDE_STREAMS = 3
 
@@ -279,37 +281,47 @@ def side_streams(device, n):
         # a first call inside a graph capture cannot synchronise, i.e. cannot probe: plain streams for this capture, the pool stays unchosen
         return [torch.cuda.Stream(device=idx) for _ in range(n)]
     if pool is None:
-        with torch.cuda.device(idx):
-            cur = torch.cuda.current_stream(idx)
-            kernels, usec, wgs = 10, 20, 64
-            alone = kernels * usec * 1e-3                       # one train: 0.2 ms; measured: 0.26 - 0.27 ms for two trains side by side,
-            limit = 2.0 * alone                                 # 0.55 - 0.60 ms when the two queues share a pipe or the streams a queue
-            pool, tried, rejected = [], 0, []
-            while len(pool) < MAX_SIDE_STREAMS and tried < 12:
-                st = torch.cuda.Stream(device=idx)
-                tried += 1
-                worst = max(_pair_ms(st, o, kernels, usec, wgs) for o in [cur] + pool)
-                if worst <= limit:
-                    pool.append(st)
-                else:
-                    rejected.append(round(worst, 3))
-            probed = len(pool)
-            while len(pool) < MAX_SIDE_STREAMS:                 # nothing better found: plain streams (and say so)
-                pool.append(torch.cuda.Stream(device=idx))
-            SIDE_STREAM_REPORT[idx] = {'candidates': tried, 'kept_by_probe': probed, 'rejected_pair_ms': rejected, 'limit_ms': round(limit, 3)}
-            if probed < MAX_SIDE_STREAMS:
-                import warnings
-                warnings.warn('diff_vit_amd: only %d of %d side streams run beside the caller\'s stream on device %d (other streams of the '
-                              'process hold the hardware queues): the sliced forward may run below the one-stream rate; pass n_streams=1'
-                              % (probed, MAX_SIDE_STREAMS, idx), RuntimeWarning, stacklevel=3)
-        _SIDE_STREAMS[idx] = pool
+        with _SIDE_LOCK:
+            pool = _SIDE_STREAMS.get(idx)
+            if pool is None:
+                pool = _SIDE_STREAMS[idx] = _choose_side_streams(idx)
     if n > MAX_SIDE_STREAMS:
         import warnings
         warnings.warn('%d side streams: with the caller\'s stream more than four streams carry work, and the step collapses to about half its '
                       'speed (profiles/r04_slices.txt); %d is the useful maximum' % (n, MAX_SIDE_STREAMS), RuntimeWarning, stacklevel=3)
-        while len(pool) < n:
-            pool.append(torch.cuda.Stream(device=idx))
+        with _SIDE_LOCK:
+            while len(pool) < n:
+                pool.append(torch.cuda.Stream(device=idx))
     return pool[:n]
+
+
+def _choose_side_streams(idx):
+    """probe up to twelve candidate streams against the caller's stream and against each other (see above); ~10 ms, once"""
+    import torch
+    with torch.cuda.device(idx):
+        cur = torch.cuda.current_stream(idx)
+        kernels, usec, wgs = 10, 20, 64
+        alone = kernels * usec * 1e-3                       # one train: 0.2 ms; measured: 0.26 - 0.27 ms for two trains side by side,
+        limit = 2.0 * alone                                 # 0.55 - 0.60 ms when the two queues share a pipe or the streams a queue
+        pool, tried, rejected = [], 0, []
+        while len(pool) < MAX_SIDE_STREAMS and tried < 12:
+            st = torch.cuda.Stream(device=idx)
+            tried += 1
+            worst = max(_pair_ms(st, o, kernels, usec, wgs) for o in [cur] + pool)
+            if worst <= limit:
+                pool.append(st)
+            else:
+                rejected.append(round(worst, 3))
+        probed = len(pool)
+        while len(pool) < MAX_SIDE_STREAMS:                 # nothing better found: plain streams (and say so)
+            pool.append(torch.cuda.Stream(device=idx))
+        SIDE_STREAM_REPORT[idx] = {'candidates': tried, 'kept_by_probe': probed, 'rejected_pair_ms': rejected, 'limit_ms': round(limit, 3)}
+        if probed < MAX_SIDE_STREAMS:
+            import warnings
+            warnings.warn('diff_vit_amd: only %d of %d side streams run beside the caller\'s stream on device %d (other streams of the '
+                          'process hold the hardware queues): the sliced forward may run below the one-stream rate; pass n_streams=1'
+                          % (probed, MAX_SIDE_STREAMS, idx), RuntimeWarning, stacklevel=3)
+    return pool
 
 
 _COPY_STREAM = {}          # device index -> number of input pipelines currently copying on the pool's third side stream
