@@ -355,3 +355,19 @@ def release_copy_stream(device):
 def compute_side_streams(device):
     """side streams the sliced forward may use on ``device``: MAX_SIDE_STREAMS, one less while a ``copy_stream`` is handed out"""
     return MAX_SIDE_STREAMS - (1 if _COPY_STREAM.get(_dev_index(device), 0) > 0 else 0)
+
+
+# ---- host threads that enqueue the side streams' slices (FrozenPlan.forward_streams) ----------------------------------------------------
+THREADED_ENQUEUE = os.environ.get('P2V_THREADED_ENQUEUE', '1') != '0'
+_ENQUEUE_POOL = None
+
+
+def enqueue_pool():
+    """MAX_SIDE_STREAMS daemon worker threads, created on first use"""
+    global _ENQUEUE_POOL
+    if _ENQUEUE_POOL is None:
+        with _SIDE_LOCK:
+            if _ENQUEUE_POOL is None:
+                from concurrent.futures import ThreadPoolExecutor
+                _ENQUEUE_POOL = ThreadPoolExecutor(MAX_SIDE_STREAMS, thread_name_prefix='p2v-enqueue')
+    return _ENQUEUE_POOL
