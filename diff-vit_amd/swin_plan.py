@@ -389,17 +389,29 @@ class SwinPlan:
             raise AssertionError('slices %r do not cover a batch of %d' % (list(slices), B))
         self._streams = E.side_streams(self.device, n_streams)          # the process's shared side streams of this device (engine.side_streams)
         cur = torch.cuda.current_stream(self.device)
-        outs, lo = [], 0
+        parts, lo = [], 0
         for i, n_i in enumerate(slices):
-            xi = images[lo:lo + n_i]
+            parts.append(images[lo:lo + n_i])
             lo += n_i
-            if i < n_streams:
-                st = self._streams[i]
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    outs.append(self._replay(xi, i + 1))
-            else:                                      # the caller's own stream (slot 0: the single-stream record of that batch size)
-                outs.append(self._replay(xi, 0))
+        for st in self._streams[:min(n_streams, len(slices))]:
+            st.wait_stream(cur)
+
+        def on_side_stream(i, worker):
+            if worker:
+                torch.cuda.set_device(self.device)     # (current device and current stream are per-thread settings)
+            with torch.cuda.stream(self._streams[i]):
+                return self._replay(parts[i], i + 1)
+
+        # one host thread per side stream once the launch sequences are recorded (the replay is one C call of ~1 ms of host time per slice),
+        # like FrozenPlan.forward_streams; slices beyond the side streams run on the caller's own stream (slot 0: its single-stream record)
+        n_side = min(n_streams, len(slices))
+        recorded = all((parts[i].shape[0], i + 1, True) in self._recorded for i in range(n_side))
+        if E.THREADED_ENQUEUE and recorded and not torch.cuda.is_current_stream_capturing():
+            futs = [E.enqueue_pool().submit(on_side_stream, i, True) for i in range(n_side)]
+            tail = [self._replay(xi, 0) for xi in parts[n_side:]]
+            outs = [f.result() for f in futs] + tail
+        else:
+            outs = [on_side_stream(i, False) for i in range(n_side)] + [self._replay(xi, 0) for xi in parts[n_side:]]
         for st in self._streams[:min(n_streams, len(slices))]:
             cur.wait_stream(st)
         for o in outs:
