@@ -442,11 +442,12 @@ const char* p2v_last_error(void);
 int p2v_abi_version(void);
 
 /* Scheduling / A-B switches of the process (also read once from the environment: P2V_LN_GEMM, P2V_LN_GEMM_V, P2V_LN_GENERIC,
- * P2V_LN_ROWS, P2V_ATTN_WAVES, P2V_GEMM_STAGES, P2V_GEMM_TILE).  None of them changes a result - every variant is bit-identical and is driven
- * through this call by the parity tests:
- *   "ln_gemm" 0/1 (fuse LayerNorm into qkv / fc1), "ln_gemm_version" 1/2 (4-wave / 8-wave pipelined fused kernel),
+ * P2V_LN_ROWS, P2V_ATTN_WAVES, P2V_GEMM_TILE, P2V_RESID_PRE, P2V_LN_PRE, P2V_ATTN_STREAM).  None of them changes a result - every variant is
+ * bit-identical and is driven through this call by the parity tests (profiles/r04_alt_paths.txt: the whole GPU suite on the alternatives):
+ *   "ln_gemm" 0/1 (fuse LayerNorm into qkv / fc1), "ln_gemm_version" 1/2/3 (round-2 4-wave / pipelined 4-wave (default) / 8-wave fused kernel),
  *   "ln_generic" 0/1 (generic LayerNorm chain), "ln_rows" 1..64, "attn_waves" 4..8,
- *   "gemm_tile" 0/128/256 (tile height of the layer GEMMs; 0 = 256 rows when the grid still fills the chip). */
+ *   "gemm_tile" 0/128/256 (tile height of the layer GEMMs; 0 = 256 rows when the grid still fills the chip),
+ *   "resid_pre" 0/1 (use p2v_epilogue.resid_tab), "ln_pre" 0/1 (use p2v_ln.pre), "attn_stream" 0/1 (streaming attention kernel everywhere). */
 int p2v_set_tuning(const char* name, int value);
 
 #ifdef __cplusplus
