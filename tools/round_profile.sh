@@ -15,6 +15,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_tra
 cp $R/gpurun_out/${TAG}_trace/*/*kernel_stats.csv $R/gpurun_out/${TAG}_kernel_stats.csv
 head -12 $R/gpurun_out/${TAG}_kernel_stats.csv | cut -c1-150
 rm -rf $R/gpurun_out/${TAG}_trace      # the raw trace is tens of MB; only the summary is kept
+# the same launches ALONE: one 68-image slice per step on one stream (the launch size of the default run's slices) - the average durations of this
+# trace are what bench.py's isolated `avg_launch_us` must agree with; in the trace above the slices overlap (worker threads keep four queues fed
+# even under the profiler), so its averages are the under-overlap durations and its minima the isolated ones
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace1 -- python3 $R/bench.py --batch 68 --streams 1 --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${TAG}_trace1.log 2>&1
+cp $R/gpurun_out/${TAG}_trace1/*/*kernel_stats.csv $R/gpurun_out/${TAG}_kernel_stats_isolated.csv
+head -8 $R/gpurun_out/${TAG}_kernel_stats_isolated.csv | cut -c1-150
+rm -rf $R/gpurun_out/${TAG}_trace1
 PMC_BATCH=68 bash $R/tools/pmc.sh > $R/gpurun_out/${TAG}_pmc.log 2>&1
 python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc > $R/gpurun_out/${TAG}_pmc_summary.txt
 cp $R/gpurun_out/pmc/summary.json $R/gpurun_out/${TAG}_pmc_summary.json
