@@ -329,10 +329,11 @@ def main():
     # it is reported as `event_gap_us` for orientation and NOT subtracted: two bare events cost more (4 - 5 us) than the pair adds around a kernel
     gap = sorted(gaps)[len(gaps) // 2] if gaps else 0.0
     # What the event pair adds to an interval WITH a kernel in it, calibrated on a kernel of known duration: k_stream_probe waits 20.0 us on the
-    # constant-rate counter and rocprofv3 --kernel-trace reports it as PROBE_KERNEL_US (profiles/r04_kernel_stats.csv: 21.8 us average over 360
-    # launches, 64 workgroups); the same event chain around a train of them gives the interval, and the difference is subtracted from every
-    # isolated interval so that `avg_launch_us` is the kernel's duration as the profiler sees it (before: +1.7 us = 6 - 9 % on these launches)
-    PROBE_KERNEL_US = 21.8
+    # constant-rate counter and rocprofv3 --kernel-trace reports it as PROBE_KERNEL_US (profiles/r04_kernel_stats_isolated.csv: 21.1 us average
+    # over the 42 launches of exactly this train, 64 workgroups, alone on the stream); the same event chain around the train gives the interval,
+    # and the difference is subtracted from every interval so that `avg_launch_us` is the kernel's duration as the profiler sees it
+    # (uncorrected: +3 us = 11 - 14 % on these launches)
+    PROBE_KERNEL_US = 21.1
     with torch.cuda.device(dev):
         st_cur = torch.cuda.current_stream(dev)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
