@@ -1,7 +1,9 @@
-import sys, numpy as np, torch
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+"""GPU box: the product's calibration of DeiT-S (harness.calibrate_model, where='host' and where='model') against the REAL reference's calibration
+state in tests/golden/deit_small.npz: tensors equal, power-of-two exponents that moved, PTF factors (profiles/r02_calibration_agreement.txt)."""
+import os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import diff_vit_amd as dva
-g=np.load('/root/repo/tests/golden/deit_small.npz')
+g=np.load(os.path.join(ROOT, 'tests', 'golden', 'deit_small.npz'))
 arch=dva.synth.ARCHS['deit_small']; seed=int(g['seed'])
 ref={k[len('calib/'):]:g[k] for k in g.files if k.startswith('calib/')}
 x=dva.synth.images(seed,int(g['n_calib']),224)

@@ -1,3 +1,4 @@
+"""GPU: largest |fast GELU - fp64 GELU| per input range (p2v_gelu_err_sweep), the bound behind the arithmetic GELU epilogue's margin test."""
 import ctypes as C, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import diff_vit_amd as dva
