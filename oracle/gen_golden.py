@@ -1,6 +1,6 @@
 """Generate tests/golden/*.npz by RUNNING THE REAL REFERENCE (imported from /root/reference) on CPU.
 
-Run once in the build container:   python oracle/gen_golden.py [micro|deit_small|deit_small_margin|vit_base|deit_tiny|deit_tiny_fp|kat|all]
+Run once in the build container:   python oracle/gen_golden.py [micro|deit_small|deit_small_margin|deit_small_exact|vit_base|deit_tiny|deit_tiny_fp|kat|all]
 
 Nothing of the reference is copied: only its inputs and outputs (data) are stored.  The reference
 hard-codes ``.cuda()`` in its forward (e.g. models/vit_fquant.py:206, quantizer/uniform.py:85), which
@@ -289,6 +289,53 @@ def gen_kat(ref):
     print('kat_ops: wrote %d arrays' % len(out))
 
 
+def gen_exact_images(ref, n_candidates=48, keep=8):
+    """BASELINE config 2 (DeiT-S, the headline shape) with evaluation images on which NO platform-dependent rounding of the reference flips a
+    code: the canonical oracle - and therefore the HIP engine - must equal the REAL reference on every logit.  Same weights and calibration
+    images as deit_small.npz (seed 3); candidates are the generator's images 2000 ...; an image is kept for a bit list when all 1000 logits agree."""
+    t0 = time.time()
+    arch, seed = synth.ARCHS['deit_small'], 3
+    sd = synth.vit_state_dict(arch, seed)
+    model = build_ref(arch, sd, ref)
+    x_cal = synth.images(seed, 2, 224)
+    with torch.no_grad():
+        model.model_open_calibrate()
+        model.model_open_last_calibrate()
+        model(x_cal, plot=False)
+        model.model_close_calibrate()
+        model.model_quant()
+    calib = oracle.extract_calib(model)
+    print('deit_small_exact: reference calibrated in %.1fs' % (time.time() - t0))
+    orc = oracle.OracleViT(arch, sd)
+    orc.calib = calib
+    mixed = [8 if (i * 7 + 3) % 5 < 3 else 4 for i in range(50)]
+    cfgs = {'q8': [8] * 50, 'q4': [4] * 50, 'qmix': mixed}
+    s_o = float(calib['act_out'].reshape(-1)[0])
+    ref_logits = {t: [] for t in cfgs}
+    exact = {t: [] for t in cfgs}
+    for lo in range(0, n_candidates, 8):
+        x = synth.images(seed, 8, 224, offset=2000 + lo)
+        for tag, bc in cfgs.items():
+            with torch.no_grad():
+                r = model(x, bc, False)[0]
+            o = orc.quant_forward(x, bc)
+            same = (torch.round((o - r) / s_o) == 0).all(dim=1)
+            ref_logits[tag].append(r)
+            exact[tag] += [lo + i for i in range(8) if bool(same[i])]
+        print('  candidates %d..%d: exact so far %s (%.0fs)' % (lo, lo + 7, {t: len(v) for t, v in exact.items()}, time.time() - t0), flush=True)
+    out = {'seed': np.int64(seed), 'first_offset': np.int64(2000), 'n_candidates': np.int64(n_candidates), 'bit_qmix': np.array(mixed, dtype=np.int8)}
+    for k, v in oracle.flatten_calib(calib).items():
+        out['calib/' + k] = v.numpy()
+    for tag in cfgs:
+        allr = torch.cat(ref_logits[tag], 0)
+        idx = exact[tag][:keep]
+        out['exact_images/' + tag] = np.array(idx, dtype=np.int64)                       # candidate numbers (image = offset 2000 + number)
+        out['n_exact/' + tag] = np.int64(len(exact[tag]))                                # of n_candidates
+        out['logits/' + tag] = allr[idx].numpy() if idx else np.zeros((0, 1000), dtype=np.float32)
+    np.savez_compressed(os.path.join(GOLD, 'deit_small_exact.npz'), **out)
+    print('deit_small_exact: wrote; exact images per list:', {t: exact[t] for t in cfgs}, '(%.0fs)' % (time.time() - t0))
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     torch.manual_seed(0)
@@ -320,6 +367,8 @@ def main():
     if what in ('vit_base', 'all'):
         # BASELINE configs 3 / 5 (ViT-B and DeiT-B share the architecture: 768 wide, 12 heads, fc2 with K = 3072): logits and the top-level taps
         gen_model_fixture('vit_base', synth.ARCHS['vit_base'], 13, 2, 2, False, lambda n: '.' not in n, ref)
+    if what in ('deit_small_exact', 'all'):
+        gen_exact_images(ref)
     if what in ('deit_small_margin', 'all'):
         # same architecture, seed 5, 8 evaluation images, a head with planted classes (plant_head_margin): top-1 testable at 4 bits
         gen_model_fixture('deit_small_margin', synth.ARCHS['deit_small'], 5, 2, 8, False, lambda n: '.' not in n, ref, sd_hook=plant_head_margin)

@@ -191,6 +191,29 @@ def test_other_architectures_vs_oracle_and_golden(dva, oracle, synth, name):
             assert np.array_equal(out.numpy(), g['logits/' + tag]), tag             # HIP engine == REAL reference, every logit
 
 
+def test_deit_small_exact_images_equal_the_reference_on_gpu(dva, oracle, synth):
+    """THE HEADLINE CONFIGURATION against the real reference, logit for logit: on the evaluation images of tests/golden/deit_small_exact.npz
+    (those of 48 candidates on which no platform-dependent rounding of the reference's torch-CPU run flips a code: 13 for [8]*50, 11 for
+    [4]*50, 11 for the mixed list; eight kept per list) the HIP engine's logits EQUAL THE REAL REFERENCE'S for every class - DeiT-S, 224^2,
+    the reference's own calibration state, through the sliced multi-stream forward as well."""
+    g = load_golden('deit_small_exact')
+    arch = synth.ARCHS['deit_small']
+    seed = int(g['seed'])
+    plan = dva.FrozenPlan(arch, synth.vit_state_dict(arch, seed), golden_calib(g, oracle))
+    for tag in ('q8', 'q4', 'qmix'):
+        idx = [int(i) for i in g['exact_images/' + tag]]
+        assert len(idx) == 8
+        x = torch.cat([synth.images(seed, 1, 224, offset=int(g['first_offset']) + i) for i in idx]).cuda()
+        bits = _bits(g, tag, 50)
+        out = plan.forward(x, bits).cpu()
+        assert np.array_equal(out.numpy(), g['logits/' + tag]), (tag, int((out.numpy() != g['logits/' + tag]).sum()))
+        big = x.repeat(16, 1, 1, 1)                                              # 128 images: three slices on their streams
+        lg = torch.empty(128, 1000, device='cuda')
+        plan.forward_streams(big, bits, lg)
+        assert len(plan.slice_sizes(128)) == 3
+        assert np.array_equal(lg.cpu().numpy(), np.tile(g['logits/' + tag], (16, 1))), tag
+
+
 def test_deit_small_margin_top1_identical_on_gpu(dva, oracle, synth):
     """the HIP engine on the planted-margin DeiT-S fixture (tests/golden/deit_small_margin.npz): logits bit-equal to the canonical
     oracle, and top-1 IDENTICAL to the real reference's on all 8 images for [8]*50, [4]*50 and the mixed list."""

@@ -173,6 +173,24 @@ def test_other_architectures_are_the_reference(oracle, synth, name):
             assert np.array_equal(out.numpy(), g['logits/' + tag]), tag          # canonical oracle == REAL reference, every logit
 
 
+def test_deit_small_exact_images_equal_the_reference(oracle, synth):
+    """BASELINE config 2 (the headline shape) on evaluation images where no platform-dependent rounding of the reference flips a code
+    (tests/golden/deit_small_exact.npz: 13 / 11 / 11 of 48 candidate images for [8]*50 / [4]*50 / the mixed list; eight kept per list):
+    the canonical oracle equals the REAL reference on EVERY logit.  The GPU twin asserts the same of the HIP engine."""
+    g = load_golden('deit_small_exact')
+    arch = synth.ARCHS['deit_small']
+    sd = synth.vit_state_dict(arch, int(g['seed']))
+    orc = oracle.OracleViT(arch, sd)
+    orc.calib = golden_calib(g, oracle)
+    cfgs = {'q8': [8] * 50, 'q4': [4] * 50, 'qmix': [int(b) for b in g['bit_qmix']]}
+    for tag in ('q8', 'q4'):
+        idx = [int(i) for i in g['exact_images/' + tag]]
+        assert len(idx) == 8 and int(g['n_exact/' + tag]) >= 8
+        x = torch.cat([synth.images(int(g['seed']), 1, 224, offset=int(g['first_offset']) + i) for i in idx[:4]])
+        out = orc.quant_forward(x, cfgs[tag])
+        assert np.array_equal(out.numpy(), g['logits/' + tag][:4]), tag
+
+
 def test_deit_small_margin_top1_identical(oracle, synth):
     """north_star's 'identical top-1 indices' at DeiT-S size, made testable: the head of this fixture carries one planted class per
     evaluation image (oracle/gen_golden.py::plant_head_margin), so every top-1 leads the runner-up by > 80 codes while the
