@@ -168,6 +168,11 @@ class PatchMerging(nn.Module):
         assert H % 2 == 0 and W % 2 == 0, f'x size ({H}*{W}) are not even.'
         x = x.view(B, H, W, C)
         x = torch.cat([x[:, 0::2, 0::2, :], x[:, 1::2, 0::2, :], x[:, 0::2, 1::2, :], x[:, 1::2, 1::2, :]], -1).view(B, -1, 4 * C)
+        # in_scale_expand = 4: the input scales of the four gathered pixels, channel block by channel block.  The reference writes
+        # `self.norm(x, last_quantizer, self.qact1.quantizer, 4)` (swin_quant.py:457), which in THIS fork's QIntLayerNorm signature
+        # (layers.py:241-246: out_quantizer_scale comes before in_scale_expand) puts the 4 into out_quantizer_scale and divides 4C
+        # channels by C scales - one more reason its Swin cannot run as shipped (SURVEY 8c caveat 3).  The intent (FQ-ViT's own
+        # PatchMerging) is built; the integer LayerNorm with in_scale_expand = 4 is pinned by the real class (tests/golden/kat_ops.npz).
         x = self.qact1(self.norm(x, last_quantizer, self.qact1.quantizer, None, 4))
         return self.qact2(self.reduction(x))
 
